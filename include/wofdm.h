@@ -1,0 +1,144 @@
+/*
+ * wofdm.h -- C ABI of libwofdm_hip.so, the MI355X (gfx950) implementation of
+ * the w-OFDM Monte-Carlo BER hot path.
+ *
+ * The reference has no FFI: the hot path is a MATLAB local function and a
+ * Python method.  The entry points below are what a binding for that path
+ * replaces:
+ *
+ *   wofdm_run              <- ber = run_simulation(ensemble, symbolsPerTx, bitsPerSubcarrier,
+ *                                numSubcar, cpLength, csLength, windowTx, channel, snr, tailTx,
+ *                                tailRx, windowRx, prefixRemovalLength, circularShiftLength)
+ *                             matlab/main_BER_calculation.m:230-274, batched over the
+ *                             (window pair x SNR x channel) loop nest of lines 64-201;
+ *                          <- wOFDMSystem.run_simulation(channel_models, window_tx, window_rx,
+ *                                ensemble, snr_arr, no_symbols)
+ *                             python/ofdm_utils/wofdm_simulation.py:432-481 (loop nest 168-242)
+ *   wofdm_plan_*           <- the same, split into "upload constants once" + "launch a frame
+ *                             range", so a driver can shard frames over GPUs and keep the
+ *                             constants resident in HBM
+ *   wofdm_*_injected       <- the same frame pipeline with the random draws
+ *                             (main_BER_calculation.m:246,290 / wofdm_simulation.py:136,183)
+ *                             supplied by the caller -- parity / HBM-streaming mode
+ *
+ * Conventions: plain pointers and sizes only.  `*_dev` pointers are device (HBM) addresses
+ * on the plan's GPU, all others are host addresses.  All pointers are caller-owned and not
+ * retained after the call returns (plans copy what they need).  Every function returns
+ * WOFDM_OK (0) or a negative WOFDM_E_* code; wofdm_last_error() gives the message of the
+ * last failure on the calling thread.  There is no CPU fallback: without a usable gfx950
+ * device every compute entry point fails with WOFDM_E_HIP.
+ *
+ * A *cell* is one (window pair, SNR, channel) triple, cell = (pair*n_snr + snr)*n_channels
+ * + channel.  counts[cell][4] = {bit errors, bits, symbol errors, symbols} over the data
+ * symbols 1..S-1 of every frame (symbol 0 is the pilot, main_BER_calculation.m:250,266-268);
+ * counters are ACCUMULATED into, never reset by a launch.
+ */
+#ifndef WOFDM_H
+#define WOFDM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOFDM_ABI_VERSION 1
+
+#define WOFDM_OK            0
+#define WOFDM_E_INVALID    -1   /* NULL pointer / inconsistent lengths                  */
+#define WOFDM_E_UNSUPPORTED -2  /* N, k, S, taps or tails outside the built kernels     */
+#define WOFDM_E_HIP        -3   /* HIP runtime error (no device, launch failure, ...)   */
+#define WOFDM_E_NOMEM      -4
+
+#define WOFDM_MAX_TAPS     21   /* taps of the reference's 200 ns Veh-A lines           */
+#define WOFDM_MAX_SYMS     16   /* symbolsPerTx (matlab/window_optimization.m:39-47)    */
+
+typedef struct wofdm_cfg {
+    int32_t  n_fft;            /* N: 64, 128, 256, 512, 1024                                */
+    int32_t  bits_per_sc;      /* k: 2, 4, 6 (QPSK, 16-QAM, 64-QAM, MATLAB Gray labels)     */
+    int32_t  syms_per_frame;   /* S: 2..16, symbol 0 = pilot                                */
+    int32_t  cp, cs;           /* mu, rho                                                   */
+    int32_t  tail_tx, tail_rx; /* beta, delta (delta even)                                  */
+    int32_t  prefix_rm;        /* gamma; N + delta + gamma == N + mu + rho - beta required  */
+    int32_t  circ_shift;       /* kappa                                                     */
+    int32_t  n_taps;           /* L <= WOFDM_MAX_TAPS                                       */
+    int32_t  n_channels, n_snr, n_window_pairs;
+    int32_t  noise_before_truncate; /* 1: MATLAB order (m:260-261); 0: Python (py:208-215)  */
+    uint64_t frames_per_cell;  /* frames [frame_offset, frame_offset+frames_per_cell)       */
+    uint64_t frame_offset;     /*   of every cell (global frame index keys the RNG)         */
+    uint64_t seed;
+} wofdm_cfg;
+
+/* Optional stage dump of ONE frame (host float buffers, complex = interleaved re,im;
+ * any pointer may be NULL).  Same stages as the oracle's dump. */
+typedef struct wofdm_dump {
+    uint8_t *labels_tx;  /* [S][N]                                      */
+    float   *X;          /* [S][N][2]                                   */
+    float   *tx;         /* [beta + S*B][2]                             */
+    float   *conv;       /* [T + L - 1][2]                              */
+    float   *rx;         /* [S*B][2]                                    */
+    float   *Y;          /* [S][N][2]                                   */
+    float   *Xhat;       /* [S-1][N][2]                                 */
+    uint8_t *labels_rx;  /* [S-1][N]                                    */
+    float   *gain;       /* [1]                                         */
+    float   *unit_noise; /* [noise_len][2] the unit normals the kernel used */
+} wofdm_dump;
+
+typedef struct wofdm_plan wofdm_plan;
+
+int         wofdm_version(void);
+int         wofdm_device_count(void);            /* < 0 on HIP failure                    */
+const char *wofdm_last_error(void);
+int         wofdm_noise_len(const wofdm_cfg *cfg);/* unit-noise samples per frame         */
+
+/* Upload windows [pairs][P] / [pairs][N+delta], channels [n_channels][L][2] and SNR points
+ * [n_snr] (dB) to `device` and select the kernel.  frames_per_cell / frame_offset of cfg are
+ * ignored here (given per launch). */
+int wofdm_plan_create(wofdm_plan **plan, const wofdm_cfg *cfg, int device,
+                      const float *w_tx, const float *w_rx, const float *h,
+                      const float *snr_db);
+int wofdm_plan_destroy(wofdm_plan *plan);
+
+/* Asynchronous launch on `stream` (a hipStream_t, NULL = default stream): simulate frames
+ * [frame_offset, frame_offset+frames_per_cell) of every cell with the on-device Philox4x32-10
+ * streams and add into counts_dev[cells][4] (uint64, device memory of the plan's GPU). */
+int wofdm_plan_launch(wofdm_plan *plan, uint64_t frame_offset, uint64_t frames_per_cell,
+                      uint64_t *counts_dev, void *stream);
+
+/* Same, bracketed by HIP events on `stream`; blocks until the kernel finished and returns
+ * its duration in milliseconds. */
+int wofdm_plan_launch_timed(wofdm_plan *plan, uint64_t frame_offset, uint64_t frames_per_cell,
+                            uint64_t *counts_dev, void *stream, float *kernel_ms);
+
+/* Injected randomness, device buffers: labels_dev[cells][frames][S][N] (uint8),
+ * unit_noise_dev[cells][frames][noise_len][2] (float, N(0,1) per component). */
+int wofdm_plan_launch_injected(wofdm_plan *plan, uint64_t frames_per_cell,
+                               const uint8_t *labels_dev, const float *unit_noise_dev,
+                               uint64_t *counts_dev, void *stream);
+
+/* Run ONE frame of `cell` on the GPU and copy its intermediate stages to host buffers.
+ * labels / unit_noise: host arrays to inject, or NULL to use the Philox streams of
+ * (seed, cell, frame).  counts[4] (host) accumulated into. */
+int wofdm_plan_dump_frame(wofdm_plan *plan, uint32_t cell, uint64_t frame,
+                          const uint8_t *labels, const float *unit_noise,
+                          uint64_t *counts, wofdm_dump *out);
+
+/* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
+ * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
+int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
+
+/* One-shot, host pointers in / host counters out (synchronous):
+ * counts[pairs][n_snr][n_channels][4] accumulated into. */
+int wofdm_run(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+              const float *h, const float *snr_db, uint64_t *counts);
+int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+                       const float *h, const float *snr_db, const uint8_t *labels,
+                       const float *unit_noise, uint64_t *counts);
+
+/* Philox4x32-10 known-answer hook (runs one block on the GPU). */
+int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

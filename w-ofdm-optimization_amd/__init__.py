@@ -1,0 +1,20 @@
+"""wofdm_amd -- MI355X-native windowed-OFDM Monte-Carlo BER hot path.
+
+The directory is named ``w-ofdm-optimization_amd`` (not an importable identifier); import it
+as ``wofdm_amd`` through the shim module at the repository root.
+
+  variants     structure table, raised-cosine / optimised window vectors  (host, numpy)
+  simulation   run_simulation / wOFDMSystem / simulation_fun mirrors + Plan (ctypes -> HIP)
+  distributed  frame-range sharding + counter all-reduce
+  _lib         ctypes binding of libwofdm_hip.so (include/wofdm.h)
+"""
+from . import variants  # noqa: F401
+from . import _lib  # noqa: F401
+from . import distributed  # noqa: F401
+from .simulation import (Plan, ber_for_window_file, error_rates, make_cfg,  # noqa: F401
+                         results_from_counts, run_counts, run_counts_injected, run_simulation,
+                         save_ber_results, simulation_fun, wOFDMSystem)
+from .variants import (SYSTEMS, Structure, calculate_parameters, expand_rx_window,  # noqa: F401
+                       expand_tx_window, make_structure, rx_rc_window, tx_rc_window)
+
+__version__ = "0.1.0"

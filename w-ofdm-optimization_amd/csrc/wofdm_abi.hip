@@ -1,0 +1,445 @@
+// wofdm_abi.hip -- extern "C" boundary of libwofdm_hip.so (declared in include/wofdm.h).
+// Plans own the constants in HBM; launches are asynchronous on the caller's stream.
+#include "../../include/wofdm.h"
+#include "wofdm_kernel.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? WOFDM_E_NOMEM : WOFDM_E_HIP, "%s: %s",    \
+                        #expr, hipGetErrorString(e_));                                        \
+    } while (0)
+
+struct geom {
+    int N, k, S, mu, rho, beta, delta, gamma, kappa, L, P, B, T, NL;
+};
+
+int check_cfg(const wofdm_cfg *c, geom *g)
+{
+    if (!c) return fail(WOFDM_E_INVALID, "cfg is NULL");
+    const int N = c->n_fft;
+    if (N != 64 && N != 128 && N != 256 && N != 512 && N != 1024)
+        return fail(WOFDM_E_UNSUPPORTED, "n_fft=%d not in {64,128,256,512,1024}", N);
+    if (c->bits_per_sc != 2 && c->bits_per_sc != 4 && c->bits_per_sc != 6)
+        return fail(WOFDM_E_UNSUPPORTED, "bits_per_sc=%d not in {2,4,6}", c->bits_per_sc);
+    if (c->syms_per_frame < 2 || c->syms_per_frame > WOFDM_MAX_SYMS)
+        return fail(WOFDM_E_UNSUPPORTED, "syms_per_frame=%d not in [2,%d]", c->syms_per_frame,
+                    WOFDM_MAX_SYMS);
+    if (c->n_taps < 1 || c->n_taps > WOFDM_MAX_TAPS)
+        return fail(WOFDM_E_UNSUPPORTED, "n_taps=%d not in [1,%d]", c->n_taps, WOFDM_MAX_TAPS);
+    if (c->cp < 0 || c->cs < 0 || c->tail_tx < 0 || c->tail_rx < 0 || (c->tail_rx & 1) ||
+        c->prefix_rm < 0 || c->circ_shift < 0 || c->circ_shift >= N)
+        return fail(WOFDM_E_INVALID, "negative length, odd tail_rx or circ_shift >= n_fft");
+    if (c->cp > N || c->cs > N || c->tail_rx > N)
+        return fail(WOFDM_E_INVALID, "cp, cs and tail_rx must not exceed n_fft");
+    if (c->n_channels < 1 || c->n_snr < 1 || c->n_window_pairs < 1)
+        return fail(WOFDM_E_INVALID, "n_channels, n_snr, n_window_pairs must be >= 1");
+    g->N = N; g->k = c->bits_per_sc; g->S = c->syms_per_frame;
+    g->mu = c->cp; g->rho = c->cs; g->beta = c->tail_tx; g->delta = c->tail_rx;
+    g->gamma = c->prefix_rm; g->kappa = c->circ_shift; g->L = c->n_taps;
+    g->P = N + g->mu + g->rho; g->B = g->P - g->beta; g->T = g->beta + g->S * g->B;
+    g->NL = c->noise_before_truncate ? g->T + g->L - 1 : g->S * g->B;
+    if (2 * g->beta > g->P) return fail(WOFDM_E_INVALID, "2*tail_tx exceeds the symbol length");
+    // the Rx reshape of matlab/main_BER_calculation.m:262-263 needs B == N + delta + gamma
+    if (g->B != N + g->delta + g->gamma)
+        return fail(WOFDM_E_INVALID, "n_fft+cp+cs-tail_tx (%d) != n_fft+tail_rx+prefix_rm (%d)",
+                    g->B, N + g->delta + g->gamma);
+    if (g->B > 64 * wofdm_rb(N))
+        return fail(WOFDM_E_UNSUPPORTED, "cp+cs-tail_tx=%d exceeds the 64 samples the kernel's "
+                    "FIR tiling allows", g->B - N);
+    const uint64_t cells = (uint64_t)c->n_channels * c->n_snr * c->n_window_pairs;
+    if (cells >= (1u << 28)) return fail(WOFDM_E_UNSUPPORTED, "more than 2^28 cells");
+    return WOFDM_OK;
+}
+
+}  // namespace
+
+struct wofdm_plan {
+    int device = 0;
+    wofdm_cfg cfg{};
+    geom g{};
+    uint32_t n_cells = 0;
+    float *d_wtx = nullptr, *d_wrx = nullptr, *d_nlin = nullptr;
+    float2 *d_h = nullptr;
+    wofdm_kparams base{};
+    wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};
+    int occ = 1, cus = 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, int force_grid,
+           hipStream_t stream)
+{
+    wofdm_kernel_fn fn = pl->fn[mode];
+    if (!fn) return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d", pl->g.N);
+    if (total_items == 0) return WOFDM_OK;
+    uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
+    if (grid > total_items) grid = total_items;
+    if (force_grid > 0) grid = (uint64_t)force_grid;
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
+                            dim3(64u * (unsigned)pl->g.S), args, kp.lds.bytes, stream));
+    return WOFDM_OK;
+}
+
+int check_launch_args(wofdm_plan *pl, uint64_t frames_per_cell)
+{
+    if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
+    if (frames_per_cell > (1ull << 40)) return fail(WOFDM_E_INVALID, "frames_per_cell too large");
+    return WOFDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wofdm_version(void) { return WOFDM_ABI_VERSION; }
+
+const char *wofdm_last_error(void) { return g_err; }
+
+int wofdm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(WOFDM_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int wofdm_noise_len(const wofdm_cfg *cfg)
+{
+    geom g;
+    int rc = check_cfg(cfg, &g);
+    return rc ? rc : g.NL;
+}
+
+int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const float *w_tx,
+                      const float *w_rx, const float *h, const float *snr_db)
+{
+    if (!out || !w_tx || !w_rx || !h || !snr_db) return fail(WOFDM_E_INVALID, "NULL argument");
+    *out = nullptr;
+    geom g;
+    int rc = check_cfg(cfg, &g);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(WOFDM_E_HIP, "device %d not available (%d visible); there is no CPU fallback",
+                    device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    wofdm_plan *pl = new (std::nothrow) wofdm_plan;
+    if (!pl) return fail(WOFDM_E_NOMEM, "out of host memory");
+    pl->device = device; pl->cfg = *cfg; pl->g = g;
+    pl->n_cells = (uint32_t)cfg->n_channels * cfg->n_snr * cfg->n_window_pairs;
+
+    const size_t n_wtx = (size_t)cfg->n_window_pairs * g.P;
+    const size_t n_wrx = (size_t)cfg->n_window_pairs * (g.N + g.delta);
+    std::vector<float2> hp((size_t)cfg->n_channels * WOFDM_LT, make_float2(0.f, 0.f));
+    for (int c = 0; c < cfg->n_channels; ++c)
+        for (int l = 0; l < g.L; ++l)
+            hp[(size_t)c * WOFDM_LT + l] = make_float2(h[2 * ((size_t)c * g.L + l)],
+                                                       h[2 * ((size_t)c * g.L + l) + 1]);
+    std::vector<float> nlin(cfg->n_snr);
+    for (int i = 0; i < cfg->n_snr; ++i) nlin[i] = (float)std::pow(10.0, -0.1 * (double)snr_db[i]);
+
+#define PLAN_TRY(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            wofdm_plan_destroy(pl);                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? WOFDM_E_NOMEM : WOFDM_E_HIP, "%s: %s",    \
+                        #expr, hipGetErrorString(e_));                                        \
+        }                                                                                     \
+    } while (0)
+
+    PLAN_TRY(hipMalloc(&pl->d_wtx, n_wtx * sizeof(float)));
+    PLAN_TRY(hipMalloc(&pl->d_wrx, n_wrx * sizeof(float)));
+    PLAN_TRY(hipMalloc(&pl->d_h, hp.size() * sizeof(float2)));
+    PLAN_TRY(hipMalloc(&pl->d_nlin, nlin.size() * sizeof(float)));
+    PLAN_TRY(hipMemcpy(pl->d_wtx, w_tx, n_wtx * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(pl->d_wrx, w_rx, n_wrx * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(pl->d_h, hp.data(), hp.size() * sizeof(float2), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(pl->d_nlin, nlin.data(), nlin.size() * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipEventCreate(&pl->ev0));
+    PLAN_TRY(hipEventCreate(&pl->ev1));
+
+    wofdm_kparams &kp = pl->base;
+    kp.S = g.S; kp.k = g.k; kp.mu = g.mu; kp.rho = g.rho; kp.beta = g.beta; kp.delta = g.delta;
+    kp.gamma = g.gamma; kp.kappa = g.kappa; kp.L = g.L; kp.P = g.P; kp.B = g.B; kp.T = g.T;
+    kp.NL = g.NL; kp.n_snr = cfg->n_snr; kp.n_ch = cfg->n_channels;
+    kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
+    const double a = std::sqrt(2.0 * ((1 << g.k) - 1) / 3.0);
+    kp.qam_scale = (float)(1.0 / a); kp.qam_inv = (float)a;
+    kp.lds = wofdm_make_layout(g.N, g.S, g.k, g.P, g.B, g.beta, g.delta);
+    kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
+
+    hipDeviceProp_t prop;
+    PLAN_TRY(hipGetDeviceProperties(&prop, device));
+    pl->cus = prop.multiProcessorCount;
+    if (kp.lds.bytes > (size_t)prop.sharedMemPerBlock && kp.lds.bytes > 160u * 1024u) {
+        wofdm_plan_destroy(pl);
+        return fail(WOFDM_E_UNSUPPORTED, "frame needs %zu bytes of LDS", kp.lds.bytes);
+    }
+    for (int m = 0; m < 4; ++m) {
+        pl->fn[m] = wofdm_select_kernel(g.N, m);
+        if (!pl->fn[m]) continue;
+        PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[m]),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kp.lds.bytes));
+    }
+    int occ = 0;
+    PLAN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S, kp.lds.bytes));
+    if (occ < 1) {
+        wofdm_plan_destroy(pl);
+        return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %zu bytes)", kp.lds.bytes);
+    }
+    pl->occ = occ;
+#undef PLAN_TRY
+    *out = pl;
+    return WOFDM_OK;
+}
+
+int wofdm_plan_destroy(wofdm_plan *pl)
+{
+    if (!pl) return WOFDM_OK;
+    (void)hipSetDevice(pl->device);
+    if (pl->d_wtx) (void)hipFree(pl->d_wtx);
+    if (pl->d_wrx) (void)hipFree(pl->d_wrx);
+    if (pl->d_h) (void)hipFree(pl->d_h);
+    if (pl->d_nlin) (void)hipFree(pl->d_nlin);
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    delete pl;
+    return WOFDM_OK;
+}
+
+int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
+{
+    if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
+    info[0] = pl->g.S;
+    info[1] = (int32_t)pl->base.lds.bytes;
+    info[2] = pl->cus * pl->occ;
+    info[3] = pl->occ;
+    info[4] = pl->cus;
+    return WOFDM_OK;
+}
+
+int wofdm_plan_launch(wofdm_plan *pl, uint64_t frame_offset, uint64_t frames_per_cell,
+                      uint64_t *counts_dev, void *stream)
+{
+    int rc = check_launch_args(pl, frames_per_cell);
+    if (rc) return rc;
+    if (!counts_dev) return fail(WOFDM_E_INVALID, "counts_dev is NULL");
+    HIP_TRY(hipSetDevice(pl->device));
+    wofdm_kparams kp = pl->base;
+    kp.frames_per_cell = frames_per_cell; kp.frame_offset = frame_offset;
+    kp.counts = reinterpret_cast<unsigned long long *>(counts_dev);
+    return launch(pl, WOFDM_MODE_GEN, kp, frames_per_cell * pl->n_cells, 0,
+                  static_cast<hipStream_t>(stream));
+}
+
+int wofdm_plan_launch_timed(wofdm_plan *pl, uint64_t frame_offset, uint64_t frames_per_cell,
+                            uint64_t *counts_dev, void *stream, float *kernel_ms)
+{
+    if (!pl || !kernel_ms) return fail(WOFDM_E_INVALID, "NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(hipEventRecord(pl->ev0, st));
+    int rc = wofdm_plan_launch(pl, frame_offset, frames_per_cell, counts_dev, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(pl->ev1, st));
+    HIP_TRY(hipEventSynchronize(pl->ev1));
+    HIP_TRY(hipEventElapsedTime(kernel_ms, pl->ev0, pl->ev1));
+    return WOFDM_OK;
+}
+
+int wofdm_plan_launch_injected(wofdm_plan *pl, uint64_t frames_per_cell, const uint8_t *labels_dev,
+                               const float *unit_noise_dev, uint64_t *counts_dev, void *stream)
+{
+    int rc = check_launch_args(pl, frames_per_cell);
+    if (rc) return rc;
+    if (!counts_dev || !labels_dev || !unit_noise_dev) return fail(WOFDM_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(pl->device));
+    wofdm_kparams kp = pl->base;
+    kp.frames_per_cell = frames_per_cell; kp.frame_offset = 0;
+    kp.counts = reinterpret_cast<unsigned long long *>(counts_dev);
+    kp.labels = labels_dev;
+    kp.unit_noise = reinterpret_cast<const float2 *>(unit_noise_dev);
+    return launch(pl, WOFDM_MODE_INJECT, kp, frames_per_cell * pl->n_cells, 0,
+                  static_cast<hipStream_t>(stream));
+}
+
+int wofdm_plan_dump_frame(wofdm_plan *pl, uint32_t cell, uint64_t frame, const uint8_t *labels,
+                          const float *unit_noise, uint64_t *counts, wofdm_dump *out)
+{
+    if (!pl || !counts || !out) return fail(WOFDM_E_INVALID, "NULL argument");
+    if (cell >= pl->n_cells) return fail(WOFDM_E_INVALID, "cell %u out of range", cell);
+    if ((labels == nullptr) != (unit_noise == nullptr))
+        return fail(WOFDM_E_INVALID, "inject both labels and unit_noise or neither");
+    const geom &g = pl->g;
+    HIP_TRY(hipSetDevice(pl->device));
+    const size_t SN = (size_t)g.S * g.N, CL = (size_t)g.T + g.L - 1, SB = (size_t)g.S * g.B;
+    // one device arena: [counts 4xu64][X][tx][conv][rx][Y][Xhat][noise] float2, gain, labels
+    const size_t n_f2 = SN + g.T + CL + SB + SN + SN + (size_t)g.NL;
+    const size_t bytes = 32 + n_f2 * sizeof(float2) + 16 + 2 * SN + (labels ? SN + (size_t)g.NL * 8 : 0) + 64;
+    unsigned char *arena = nullptr;
+    HIP_TRY(hipMalloc(&arena, bytes));
+    int rc = WOFDM_OK;
+    do {
+        if (hipMemset(arena, 0, bytes) != hipSuccess) { rc = fail(WOFDM_E_HIP, "hipMemset failed"); break; }
+        wofdm_kparams kp = pl->base;
+        unsigned char *ptr = arena;
+        kp.counts = reinterpret_cast<unsigned long long *>(ptr) - 4 * (size_t)cell; ptr += 32;
+        float2 *f2 = reinterpret_cast<float2 *>(ptr);
+        kp.dump.X = f2; f2 += SN;
+        kp.dump.tx = f2; f2 += g.T;
+        kp.dump.conv = f2; f2 += CL;
+        kp.dump.rx = f2; f2 += SB;
+        kp.dump.Y = f2; f2 += SN;
+        kp.dump.Xhat = f2; f2 += SN;
+        kp.dump.unit_noise = f2; f2 += g.NL;
+        kp.dump.gain = reinterpret_cast<float *>(f2);
+        unsigned char *b = reinterpret_cast<unsigned char *>(f2) + 16;
+        kp.dump.labels_tx = b; b += SN;
+        kp.dump.labels_rx = b; b += SN;
+        if (labels) {
+            uint8_t *dl = b; b += SN;
+            b = reinterpret_cast<unsigned char *>(((uintptr_t)b + 15) & ~(uintptr_t)15);
+            float2 *dn = reinterpret_cast<float2 *>(b);
+            if (hipMemcpy(dl, labels, SN, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dn, unit_noise, (size_t)g.NL * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                rc = fail(WOFDM_E_HIP, "hipMemcpy of injected inputs failed"); break;
+            }
+            kp.labels = dl; kp.unit_noise = dn;
+        }
+        kp.first_cell = cell; kp.n_cells = 1; kp.inject_base_cell = cell;
+        kp.frames_per_cell = 1; kp.frame_offset = frame;
+        rc = launch(pl, labels ? WOFDM_MODE_DUMP_INJECT : WOFDM_MODE_DUMP_GEN, kp, 1, 1, nullptr);
+        if (rc) break;
+        if (hipDeviceSynchronize() != hipSuccess) { rc = fail(WOFDM_E_HIP, "dump kernel failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        uint64_t c4[4];
+        auto down = [&](void *dst, const void *src, size_t n) {
+            return !dst || hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess;
+        };
+        bool ok = down(c4, arena, 32) && down(out->X, kp.dump.X, SN * 8) &&
+                  down(out->tx, kp.dump.tx, (size_t)g.T * 8) && down(out->conv, kp.dump.conv, CL * 8) &&
+                  down(out->rx, kp.dump.rx, SB * 8) && down(out->Y, kp.dump.Y, SN * 8) &&
+                  down(out->Xhat, kp.dump.Xhat, (SN - g.N) * 8) &&
+                  down(out->unit_noise, kp.dump.unit_noise, (size_t)g.NL * 8) &&
+                  down(out->gain, kp.dump.gain, 4) && down(out->labels_tx, kp.dump.labels_tx, SN) &&
+                  down(out->labels_rx, kp.dump.labels_rx, SN - g.N);
+        if (!ok) { rc = fail(WOFDM_E_HIP, "hipMemcpy of dump failed"); break; }
+        for (int i = 0; i < 4; ++i) counts[i] += c4[i];
+    } while (0);
+    (void)hipFree(arena);
+    return rc;
+}
+
+int wofdm_run(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+              const float *h, const float *snr_db, uint64_t *counts)
+{
+    if (!counts) return fail(WOFDM_E_INVALID, "counts is NULL");
+    wofdm_plan *pl = nullptr;
+    int rc = wofdm_plan_create(&pl, cfg, device, w_tx, w_rx, h, snr_db);
+    if (rc) return rc;
+    const size_t n = (size_t)pl->n_cells * 4;
+    uint64_t *d = nullptr;
+    std::vector<uint64_t> hc(n);
+    do {
+        if (hipMalloc(&d, n * 8) != hipSuccess || hipMemset(d, 0, n * 8) != hipSuccess) {
+            rc = fail(WOFDM_E_NOMEM, "counter allocation failed"); break;
+        }
+        rc = wofdm_plan_launch(pl, cfg->frame_offset, cfg->frames_per_cell, d, nullptr);
+        if (rc) break;
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(hc.data(), d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "kernel or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        for (size_t i = 0; i < n; ++i) counts[i] += hc[i];
+    } while (0);
+    if (d) (void)hipFree(d);
+    wofdm_plan_destroy(pl);
+    return rc;
+}
+
+int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+                       const float *h, const float *snr_db, const uint8_t *labels,
+                       const float *unit_noise, uint64_t *counts)
+{
+    if (!counts || !labels || !unit_noise) return fail(WOFDM_E_INVALID, "NULL argument");
+    wofdm_plan *pl = nullptr;
+    int rc = wofdm_plan_create(&pl, cfg, device, w_tx, w_rx, h, snr_db);
+    if (rc) return rc;
+    const size_t n = (size_t)pl->n_cells * 4;
+    const size_t frames = (size_t)pl->n_cells * cfg->frames_per_cell;
+    const size_t lb = frames * pl->g.S * pl->g.N, nb = frames * (size_t)pl->g.NL * 8;
+    uint64_t *d = nullptr;
+    uint8_t *dl = nullptr;
+    float *dn = nullptr;
+    std::vector<uint64_t> hc(n);
+    do {
+        if (hipMalloc(&d, n * 8) != hipSuccess || hipMemset(d, 0, n * 8) != hipSuccess ||
+            hipMalloc(&dl, lb ? lb : 1) != hipSuccess || hipMalloc(&dn, nb ? nb : 8) != hipSuccess) {
+            rc = fail(WOFDM_E_NOMEM, "device allocation failed"); break;
+        }
+        if (hipMemcpy(dl, labels, lb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dn, unit_noise, nb, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "upload failed"); break;
+        }
+        rc = wofdm_plan_launch_injected(pl, cfg->frames_per_cell, dl, dn, d, nullptr);
+        if (rc) break;
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(hc.data(), d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "kernel or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        for (size_t i = 0; i < n; ++i) counts[i] += hc[i];
+    } while (0);
+    if (d) (void)hipFree(d);
+    if (dl) (void)hipFree(dl);
+    if (dn) (void)hipFree(dn);
+    wofdm_plan_destroy(pl);
+    return rc;
+}
+
+int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    if (!ctr || !key || !out) return fail(WOFDM_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t hbuf[6] = {ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]};
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 10 * sizeof(uint32_t)));
+    int rc = WOFDM_OK;
+    if (hipMemcpy(d, hbuf, sizeof hbuf, hipMemcpyHostToDevice) != hipSuccess ||
+        wofdm_philox_kat_launch(d, d + 6, nullptr) != hipSuccess ||
+        hipMemcpy(out, d + 6, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(WOFDM_E_HIP, "philox KAT failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,677 @@
+// wofdm_kernel.hip -- the fused w-OFDM frame kernel for gfx950 (MI355X, CDNA4).
+//
+// One workgroup simulates one frame at a time (persistent over a strided list of
+// (cell, frame) work items); one 64-lane wavefront owns one OFDM symbol of the frame:
+//
+//   A  Philox bits -> Gray QAM (registers) -> N-point Stockham IFFT through the wave's own
+//      slice of the LDS frame buffer -> CP/CS copy x Tx window written straight from the
+//      last butterfly stage; the beta-sample fall tail goes to a side buffer
+//      (matlab/main_BER_calculation.m:246-252, 358-376, 419-439)
+//   -- barrier 1 --
+//   B  add the previous symbol's fall tail onto the own rise tail (overlap-add, m:253-259),
+//      21-tap complex FIR over the serialised frame from LDS (conv, m:260), Philox/Box-Muller
+//      unit noise for the same samples, per-wave partial signal/noise powers (add_wgn, m:277-294)
+//   -- barrier 2 --
+//   C  r = c + g n back into the own slice (truncate + reshape, m:261-263), Rx window / fold /
+//      circular shift fused into the first FFT stage's loads (m:297-355), Stockham FFT, pilot
+//      wave publishes X0/Y0 (m:266)
+//   -- barrier 3 --
+//   D  one-tap equalise, hard demap, bit/symbol error popcount in registers (m:267-272)
+//
+// No HBM traffic inside the loop in generate mode: constants come in once per cell, four
+// 64-bit counters go out once per cell.  fp32 VALU + LDS bound; no MFMA.
+#include "wofdm_kernel.h"
+#include "philox.h"
+
+namespace {
+
+__device__ __forceinline__ float uniform_f(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS traffic between lanes of ONE wave: DS ops execute in issue order, so only the
+    // compiler has to be kept from reordering across this point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// tw[] holds exp(-2 pi i m / N): forward DFT multiplies by it, inverse by its conjugate
+template <int DIR> __device__ __forceinline__ float2 twid(float2 a, float2 w)
+{
+    if (DIR < 0) return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+}
+
+template <int DIR> __device__ __forceinline__ void radix4(float2 (&u)[4])
+{
+    const float2 a0 = cadd(u[0], u[2]), a1 = csub(u[0], u[2]);
+    const float2 a2 = cadd(u[1], u[3]), d = csub(u[1], u[3]);
+    const float2 a3 = DIR < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+    u[0] = cadd(a0, a2); u[1] = cadd(a1, a3); u[2] = csub(a0, a2); u[3] = csub(a1, a3);
+}
+
+template <int N> struct geo {
+    static constexpr int NQ = N / 4;                 // radix-4 butterflies per stage
+    static constexpr int BPL = (NQ + 63) / 64;       // ... per lane
+    static constexpr int RB = N / 64 + 1;            // FIR outputs per lane
+};
+
+// Stockham autosort stages on the wave's LDS slice fb[0..N).  Lane data v[q][r] always means
+// element (lane + 64 q) + r N/4, both as the first stage's input and the last stage's output.
+template <int N, int DIR>
+__device__ __forceinline__ void fft_first(float2 (&v)[geo<N>::BPL][4], float2 *fb, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < geo<N>::BPL; ++q) {
+        const int j = lane + 64 * q;
+        if (j < geo<N>::NQ) {
+            radix4<DIR>(v[q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[4 * j + r] = v[q][r];
+        }
+    }
+    wave_sync();
+}
+
+template <int N, int NS, int DIR>
+__device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
+{
+    float2 u[geo<N>::BPL][4];
+#pragma unroll
+    for (int q = 0; q < geo<N>::BPL; ++q) {
+        const int j = lane + 64 * q;
+        if (j < geo<N>::NQ) {
+            const int k = j & (NS - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[q][r] = fb[j + r * geo<N>::NQ];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) u[q][r] = twid<DIR>(u[q][r], tw[r * k * (N / (4 * NS))]);
+            radix4<DIR>(u[q]);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < geo<N>::BPL; ++q) {
+        const int j = lane + 64 * q;
+        if (j < geo<N>::NQ) {
+            const int k = j & (NS - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[((j - k) << 2) + k + r * NS] = u[q][r];
+        }
+    }
+    wave_sync();
+}
+
+template <int N, int NS, int DIR>
+__device__ __forceinline__ void fft_mid2(float2 *fb, const float2 *tw, int lane)
+{
+    constexpr int NB = N / 2, PER = (NB + 63) / 64;
+    float2 y0[PER], y1[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int j = lane + 64 * q;
+        if (j < NB) {
+            const int k = j & (NS - 1);
+            const float2 a = fb[j];
+            const float2 b = twid<DIR>(fb[j + NB], tw[k * (N / (2 * NS))]);
+            y0[q] = cadd(a, b); y1[q] = csub(a, b);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int j = lane + 64 * q;
+        if (j < NB) {
+            const int k = j & (NS - 1);
+            fb[((j - k) << 1) + k] = y0[q];
+            fb[((j - k) << 1) + k + NS] = y1[q];
+        }
+    }
+    wave_sync();
+}
+
+template <int N, int DIR>
+__device__ __forceinline__ void fft_last(float2 (&v)[geo<N>::BPL][4], const float2 *fb,
+                                         const float2 *tw, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < geo<N>::BPL; ++q) {
+        const int j = lane + 64 * q;
+        if (j < geo<N>::NQ) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q][r] = fb[j + r * geo<N>::NQ];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) v[q][r] = twid<DIR>(v[q][r], tw[r * j]);
+            radix4<DIR>(v[q]);
+        }
+    }
+    wave_sync();
+}
+
+// registers -> (LDS stages) -> registers, natural order in and out
+template <int N, int DIR>
+__device__ __forceinline__ void fft_wave(float2 (&v)[geo<N>::BPL][4], float2 *fb, const float2 *tw,
+                                         int lane)
+{
+    fft_first<N, DIR>(v, fb, lane);
+    if constexpr (N == 64) {
+        fft_mid4<N, 4, DIR>(fb, tw, lane);
+    } else if constexpr (N == 128) {
+        fft_mid2<N, 4, DIR>(fb, tw, lane);
+        fft_mid4<N, 8, DIR>(fb, tw, lane);
+    } else if constexpr (N == 256) {
+        fft_mid4<N, 4, DIR>(fb, tw, lane);
+        fft_mid4<N, 16, DIR>(fb, tw, lane);
+    } else if constexpr (N == 512) {
+        fft_mid4<N, 4, DIR>(fb, tw, lane);
+        fft_mid2<N, 16, DIR>(fb, tw, lane);
+        fft_mid4<N, 32, DIR>(fb, tw, lane);
+    } else {
+        static_assert(N == 1024, "unsupported DFT length");
+        fft_mid4<N, 4, DIR>(fb, tw, lane);
+        fft_mid4<N, 16, DIR>(fb, tw, lane);
+        fft_mid4<N, 64, DIR>(fb, tw, lane);
+    }
+    fft_last<N, DIR>(v, fb, tw, lane);
+}
+
+// CNT consecutive FIR outputs starting at window base w (w[i] = tx[j0 - (LT-1) + i]).
+// The taps are wave-uniform and read through a noalias kernel argument, so they arrive by
+// scalar loads in SGPRs and feed v_fmac directly; nothing about them lives in VGPRs.
+template <int CNT>
+__device__ __forceinline__ void fir_chunk(const float2 *w, const float2 *__restrict__ taps,
+                                          float2 *acc)
+{
+    constexpr int LT = WOFDM_LT;
+    float2 win[CNT + LT - 1];
+#pragma unroll
+    for (int i = 0; i < CNT + LT - 1; ++i) win[i] = w[i];
+#pragma unroll
+    for (int r = 0; r < CNT; ++r) acc[r] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        const float2 t = taps[l];
+#pragma unroll
+        for (int r = 0; r < CNT; ++r) {
+            const float2 x = win[r + LT - 1 - l];
+            acc[r].x = fmaf(t.x, x.x, acc[r].x);
+            acc[r].x = fmaf(-t.y, x.y, acc[r].x);
+            acc[r].y = fmaf(t.x, x.y, acc[r].y);
+            acc[r].y = fmaf(t.y, x.x, acc[r].y);
+        }
+    }
+}
+
+template <int RB>
+__device__ __forceinline__ void fir_lane(const float2 *w, const float2 *__restrict__ taps,
+                                         float2 (&acc)[RB])
+{
+    constexpr int CH = 6, FULL = RB / CH, REM = RB % CH;
+#pragma unroll
+    for (int c = 0; c < FULL; ++c) fir_chunk<CH>(w + c * CH, taps, &acc[c * CH]);
+    if constexpr (REM != 0) fir_chunk<REM>(w + FULL * CH, taps, &acc[FULL * CH]);
+}
+
+// two complex unit normals from one Philox block (philox.h)
+__device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b)
+{
+    const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u2 = (float)b * 2.3283064365386963e-10f;
+    // -2 ln(u1) = -2 ln2 log2(u1); v_sin/v_cos take revolutions
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
+}
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ unsigned wave_sum_u(unsigned x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+template <int N, bool INJECT, bool DUMP>
+__global__ void __launch_bounds__(1024)
+wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
+                    const float *__restrict__ g_wrx, const float2 *__restrict__ g_h,
+                    const float *__restrict__ g_nlin)
+{
+    constexpr int LT = WOFDM_LT;
+    constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ, RB = geo<N>::RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    // the symbol index is wave-uniform: keep it (and everything derived from it) in SGPRs
+    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = lane0;
+    const int S = p.S, B = p.B, beta = p.beta, mu = p.mu, rho = p.rho, delta = p.delta;
+    const int gam = p.gamma, kap = p.kappa, NL = p.NL, k = p.k;
+
+    float2 *fbuf = reinterpret_cast<float2 *>(smem);
+    float2 *tailb = fbuf + p.lds.fbuf_len;
+    float2 *tw = tailb + p.lds.tail_len;
+    float2 *G = tw + p.lds.tw_len;
+    float *wtx = reinterpret_cast<float *>(G + p.lds.g_len);
+    float *wrx = wtx + p.lds.wtx_len;
+    uint32_t *bitsw = reinterpret_cast<uint32_t *>(wrx + p.lds.wrx_len);
+    float *sums = reinterpret_cast<float *>(bitsw + p.lds.bits_len);
+
+    float2 *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
+
+    for (int i = tid; i < p.lds.fbuf_len; i += blockDim.x) fbuf[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < N; i += blockDim.x) {
+        float sv, cv;
+        sincospif(-2.0f * (float)i / (float)N, &sv, &cv);
+        tw[i] = make_float2(cv, sv);
+    }
+    __syncthreads();
+
+    // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
+    const int half = k >> 1, m1 = (1 << half) - 1;
+    const uint32_t lmask = (1u << k) - 1u;
+    const float qscale = p.qam_scale, qinv = p.qam_inv;
+    const int ks = k == 6 ? 8 : k;
+    const int bps = N * ks / 128;                 // Philox blocks of data bits per symbol
+
+    // Work items (cell, frame) are walked with scalar adds/compares only: a 64-bit divide would
+    // push the (wave-uniform) loop state into VGPRs and turn every per-cell constant into a
+    // vector value.
+    const uint64_t F = p.frames_per_cell, GSTEP = gridDim.x;
+    const uint32_t cell_end = p.first_cell + p.n_cells;
+    uint32_t cell = p.first_cell;
+    uint64_t fidx = blockIdx.x;
+    int ch = 0, sn = 0, pair = 0;          // cell = (pair*n_snr + sn)*n_ch + ch
+    {
+        uint32_t c = 0;
+        while (c < p.first_cell) {
+            ++c;
+            if (++ch == p.n_ch) { ch = 0; if (++sn == p.n_snr) { sn = 0; ++pair; } }
+        }
+    }
+    auto next_cell = [&]() {
+        ++cell;
+        if (++ch == p.n_ch) { ch = 0; if (++sn == p.n_snr) { sn = 0; ++pair; } }
+    };
+    while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
+
+    uint32_t cur_cell = 0xFFFFFFFFu;
+    int cur_pair = -1;
+    uint32_t bit_err = 0, sym_err = 0, nfr = 0;
+    float nlin = 0.f;
+
+    auto flush = [&](uint32_t c) {
+        const unsigned be = wave_sum_u(bit_err), se = wave_sum_u(sym_err);
+        if (lane == 0 && s > 0) {
+            atomicAdd(&p.counts[4 * (size_t)c + 0], (unsigned long long)be);
+            atomicAdd(&p.counts[4 * (size_t)c + 2], (unsigned long long)se);
+        }
+        if (tid == 0) {
+            atomicAdd(&p.counts[4 * (size_t)c + 1], (unsigned long long)nfr * (S - 1) * N * k);
+            atomicAdd(&p.counts[4 * (size_t)c + 3], (unsigned long long)nfr * (S - 1) * N);
+        }
+        bit_err = 0; sym_err = 0; nfr = 0;
+    };
+
+    while (cell < cell_end) {
+        if (cell != cur_cell) {
+            if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
+            cur_cell = cell;
+            if (pair != cur_pair) {
+                __syncthreads();
+                // 1/N of the IDFT (dftmtx(N)'/N, m:370) is folded into the Tx window copy
+                for (int i = tid; i < p.P; i += blockDim.x)
+                    wtx[i] = g_wtx[(size_t)pair * p.P + i] * (1.0f / (float)N);
+                for (int i = tid; i < N + delta; i += blockDim.x)
+                    wrx[i] = g_wrx[(size_t)pair * (N + delta) + i];
+                __syncthreads();
+                cur_pair = pair;
+            }
+            nlin = g_nlin[sn];
+        }
+        // Hide the lane id from loop-invariant code motion: otherwise every per-lane LDS address
+        // of every stage is hoisted out of the frame loop and the kernel spills ~1500 VGPRs.
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        int ch_now = __builtin_amdgcn_readfirstlane(ch);   // same trick for the scalar tap loads
+        asm volatile("" : "+s"(ch_now));
+        const float2 *__restrict__ taps = g_h + ch_now * LT;
+        const uint64_t frame = p.frame_offset + fidx;
+        const uint32_t f_lo = (uint32_t)frame, f_hi = (uint32_t)(frame >> 32);
+        const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
+        ++nfr;
+
+        // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
+        float2 v[BPL][4];
+        uint32_t lab[BPL];
+        if (!INJECT) {
+            uint32_t *bw = bitsw + s * (bps * 4);
+            if (lane < bps) {
+                const philox_out o = philox4x32_10((uint32_t)(s * bps + lane), f_lo, f_hi,
+                                                   (WOFDM_STREAM_BITS << 28) | cell,
+                                                   p.seed_lo, p.seed_hi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bw[4 * lane + i] = o.w[i];
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            const int j = lane + 64 * q;
+            lab[q] = 0;
+            if (j < NQ) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = j + r * NQ;
+                    uint32_t L;
+                    if (INJECT) {
+                        L = p.labels[(inj * S + s) * N + n] & lmask;
+                    } else {
+                        const uint32_t bit = (uint32_t)n * (uint32_t)ks;
+                        L = (bitsw[s * (bps * 4) + (bit >> 5)] >> (bit & 31u)) & lmask;
+                    }
+                    lab[q] |= L << (8 * r);
+                    const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
+                    const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
+                    const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
+                    v[q][r] = make_float2((float)(2 * li - m1) * qscale, (float)(m1 - 2 * lq) * qscale);
+                    if (DUMP) {
+                        if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)L;
+                        if (p.dump.X) p.dump.X[s * N + n] = v[q][r];
+                    }
+                }
+            }
+        }
+
+        fft_wave<N, +1>(v, fb, tw, lane);          // v = N * x[t], t = j + r N/4
+
+        // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
+        // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
+        // overlaps the next symbol (m:253-256): parked in tailb until barrier 1.
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (j < NQ) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = j + r * NQ;
+                    const float2 x = v[q][r];
+                    auto put = [&](int i) {
+                        const float w = wtx[i];
+                        const float2 val = make_float2(w * x.x, w * x.y);
+                        if (i < B || s == S - 1) fb[i] = val;
+                        else tailb[s * beta + (i - B)] = val;
+                    };
+                    put(t + mu);
+                    if (t >= N - mu) put(t + mu - N);
+                    if (t < rho) put(t + mu + N);
+                }
+            }
+        }
+        __syncthreads();                                                     // ---- barrier 1
+
+        // ------------------------------------------------------------ B: overlap-add, FIR, noise
+        if (s > 0 && lane < beta) fb[lane] = cadd(fb[lane], tailb[(s - 1) * beta + lane]);
+        wave_sync();
+        if (DUMP) {
+            __syncthreads();
+            if (p.dump.tx)
+                for (int i = tid; i < p.T; i += blockDim.x) p.dump.tx[i] = fbuf[(LT - 1) + i];
+            __syncthreads();
+        }
+
+        const int nmain = (B + RB - 1) / RB;
+        const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
+        const int idle = 64 - nmain;
+        const int ntc = (tail_total + RB - 1) / RB;
+        const bool tail_in_idle = idle * S >= ntc;
+        int j0 = 0, cnt = 0;
+        const bool is_main = lane < nmain;
+        if (is_main) {
+            j0 = s * B + lane * RB;
+            cnt = min(RB, B - lane * RB);
+        } else if (tail_in_idle) {
+            const int c = (S - 1 - s) * idle + (lane - nmain);
+            if (c < ntc) { j0 = S * B + c * RB; cnt = min(RB, tail_total - c * RB); }
+        }
+
+        float2 acc[RB], nz[RB];
+        fir_lane<RB>(fbuf + j0, taps, acc);        // fbuf + (LT-1) + j0 - (LT-1)
+
+        if (INJECT) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                nz[r] = (r < cnt) ? p.unit_noise[inj * NL + j0 + r] : make_float2(0.f, 0.f);
+        } else {
+            constexpr int NBK = RB / 2 + 1;
+            float2 cand[2 * NBK];
+            if (cnt > 0) {
+                const uint32_t b0 = (uint32_t)j0 >> 1;
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    const philox_out o = philox4x32_10(b0 + b, f_lo, f_hi,
+                                                       (WOFDM_STREAM_NOISE << 28) | cell,
+                                                       p.seed_lo, p.seed_hi);
+                    cand[2 * b] = box_muller(o.w[0], o.w[1]);
+                    cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2 * NBK; ++b) cand[b] = make_float2(0.f, 0.f);
+            }
+            const bool odd = (j0 & 1) != 0;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float2 a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
+                const float2 c = odd ? b : a;
+                nz[r] = (r < cnt) ? c : make_float2(0.f, 0.f);
+            }
+        }
+
+        float ps = 0.f, pn = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (r < cnt) {
+                ps = fmaf(acc[r].x, acc[r].x, ps); ps = fmaf(acc[r].y, acc[r].y, ps);
+                pn = fmaf(nz[r].x, nz[r].x, pn); pn = fmaf(nz[r].y, nz[r].y, pn);
+                if (DUMP) {
+                    if (p.dump.conv) p.dump.conv[j0 + r] = acc[r];
+                    if (p.dump.unit_noise) p.dump.unit_noise[j0 + r] = nz[r];
+                }
+            }
+        }
+        if (!tail_in_idle && tail_total > 0 && s == S - 1) {
+            // rare geometry (no idle lanes): trailing samples only feed the power sums
+            for (int t = lane; t < tail_total; t += 64) {
+                const int j = S * B + t;
+                float2 c = make_float2(0.f, 0.f);
+                for (int l = 0; l < LT; ++l) {
+                    const float2 hh = taps[l];
+                    c = cadd(c, cmul(hh, fbuf[(LT - 1) + j - l]));
+                }
+                float2 nn;
+                if (INJECT) {
+                    nn = p.unit_noise[inj * NL + j];
+                } else {
+                    const philox_out o = philox4x32_10((uint32_t)j >> 1, f_lo, f_hi,
+                                                       (WOFDM_STREAM_NOISE << 28) | cell,
+                                                       p.seed_lo, p.seed_hi);
+                    nn = (j & 1) ? box_muller(o.w[2], o.w[3]) : box_muller(o.w[0], o.w[1]);
+                }
+                ps += c.x * c.x + c.y * c.y;
+                pn += nn.x * nn.x + nn.y * nn.y;
+                if (DUMP) {
+                    if (p.dump.conv) p.dump.conv[j] = c;
+                    if (p.dump.unit_noise) p.dump.unit_noise[j] = nn;
+                }
+            }
+        }
+        ps = wave_sum(ps); pn = wave_sum(pn);
+        if (lane == 0) { sums[s] = ps; sums[S + s] = pn; }
+        __syncthreads();                                                     // ---- barrier 2
+
+        // ------------------------------------------------------------ C: noise scale, Rx, FFT
+        float Ps = 0.f, Pn = 0.f;
+        for (int w = 0; w < S; ++w) { Ps += sums[w]; Pn += sums[S + w]; }
+        const float g = sqrtf(Ps * nlin / Pn);      // lengths cancel (m:289-292)
+        if (is_main) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (r < cnt) {
+                    const float2 y = make_float2(fmaf(g, nz[r].x, acc[r].x), fmaf(g, nz[r].y, acc[r].y));
+                    fb[lane * RB + r] = y;
+                    if (DUMP && p.dump.rx) p.dump.rx[s * B + lane * RB + r] = y;
+                }
+            }
+        }
+        if (DUMP && p.dump.gain && tid == 0) p.dump.gain[0] = g;
+        wave_sync();
+
+        // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
+        // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
+        const int h2 = delta >> 1;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (j < NQ) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = j + r * NQ;
+                    const int m0 = (t + kap + h2) & (N - 1);
+                    const float2 y = fb[gam + m0];
+                    const float w = wrx[m0];
+                    float2 z = make_float2(w * y.x, w * y.y);
+                    if (m0 < delta) {
+                        const float2 y2 = fb[gam + m0 + N];
+                        const float w2 = wrx[m0 + N];
+                        z.x = fmaf(w2, y2.x, z.x); z.y = fmaf(w2, y2.y, z.y);
+                    }
+                    v[q][r] = z;
+                }
+            }
+        }
+        wave_sync();
+        fft_wave<N, -1>(v, fb, tw, lane);          // v = Y[n], n = j + r N/4
+
+        if (DUMP && p.dump.Y) {
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                if (j < NQ)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.dump.Y[s * N + j + r * NQ] = v[q][r];
+            }
+        }
+        if (s == 0) {
+            // estimatedChannel = Y0 ./ X0 (m:266); we publish its reciprocal X0 ./ Y0
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                if (j < NQ) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t L = (lab[q] >> (8 * r)) & 0xFFu;
+                        const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
+                        const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
+                        const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
+                        const float2 x0 = make_float2((float)(2 * li - m1) * qscale,
+                                                      (float)(m1 - 2 * lq) * qscale);
+                        const float2 y0 = v[q][r];
+                        const float inv = 1.0f / (y0.x * y0.x + y0.y * y0.y);
+                        G[j + r * NQ] = make_float2((x0.x * y0.x + x0.y * y0.y) * inv,
+                                                    (x0.y * y0.x - x0.x * y0.y) * inv);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                     // ---- barrier 3
+
+        // ------------------------------------------------------------ D: equalise, demap, count
+        if (s > 0) {
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                if (j < NQ) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = j + r * NQ;
+                        const float2 xh = cmul(v[q][r], G[n]);
+                        int ii = (int)floorf((xh.x * qinv + (float)m1) * 0.5f + 0.5f);
+                        int qi = (int)floorf(((float)m1 - xh.y * qinv) * 0.5f + 0.5f);
+                        ii = min(max(ii, 0), m1);
+                        qi = min(max(qi, 0), m1);
+                        const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
+                        const uint32_t Ltx = (lab[q] >> (8 * r)) & 0xFFu;
+                        const uint32_t diff = Ltx ^ Lrx;
+                        bit_err += __popc(diff);
+                        sym_err += diff != 0u;
+                        if (DUMP) {
+                            if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = xh;
+                            if (p.dump.labels_rx) p.dump.labels_rx[(s - 1) * N + n] = (uint8_t)Lrx;
+                        }
+                    }
+                }
+            }
+        }
+
+        fidx += GSTEP;
+        while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
+    }
+    if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
+}
+
+__global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
+{
+    if (threadIdx.x == 0) {
+        const philox_out o = philox4x32_10(ck[0], ck[1], ck[2], ck[3], ck[4], ck[5]);
+        for (int i = 0; i < 4; ++i) out[i] = o.w[i];
+    }
+}
+
+template <int N> wofdm_kernel_fn pick(int mode)
+{
+    switch (mode) {
+    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, false, false>;
+    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, true, false>;
+    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, false, true>;
+    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, true, true>;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+wofdm_kernel_fn wofdm_select_kernel(int n_fft, int mode)
+{
+    switch (n_fft) {
+#ifdef WOFDM_ONLY_N        // developer builds: one DFT length, faster compile / readable ISA
+    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(mode);
+#else
+    case 64: return pick<64>(mode);
+    case 128: return pick<128>(mode);
+    case 256: return pick<256>(mode);
+    case 512: return pick<512>(mode);
+    case 1024: return pick<1024>(mode);
+#endif
+    }
+    return nullptr;
+}
+
+hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(philox_kat_kernel, dim3(1), dim3(64), 0, s, ctr_key_dev, out_dev);
+    return hipGetLastError();
+}
