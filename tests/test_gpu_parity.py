@@ -1,0 +1,264 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, on the same seeded
+inputs.  Integer work (Philox words, labels, bit totals) must be bit-exact; floating-point
+stages are fp32 on the GPU vs fp64 in the oracle, tolerance written per check."""
+import numpy as np
+import pytest
+
+import wofdm_amd as W
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SYSTEMS = ["wtx", "wrx", "WOLA", "CPW", "CPwtx", "CPwrx", "CP"]
+STAGE_RTOL = 2e-5          # fp32 chain of an N<=1024 FFT + 21-tap FIR vs fp64, relative to max|x|
+# wofdm_simulation.py:179-182
+SYM16 = np.array((-3-3j, -3-1j, -3+1j, -3+3j, -1-3j, -1-1j, -1+1j, -1+3j, 1-3j, 1-1j,
+                  1+1j, 1+3j, 3-3j, 3-1j, 3+1j, 3+3j))
+
+
+def _osys(st, k, S, n_taps, matlab):
+    return O.make_sys(st.n_fft, k, S, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm,
+                      st.circ_shift, n_taps, 1 if matlab else 0)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_device_present_and_philox_kat():
+    lib = W._lib.load()
+    assert lib.wofdm_device_count() >= 1, lib.wofdm_last_error()
+    import ctypes as C
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c = np.array(ctr, dtype=np.uint32); k = np.array(key, dtype=np.uint32)
+        out = np.zeros(4, dtype=np.uint32)
+        W._lib.check(lib.wofdm_philox_kat(0, c.ctypes.data, k.ctypes.data, out.ctypes.data))
+        assert tuple(int(x) for x in out) == want
+
+
+CASES = [(s, 64, 16, 2, 1) for s in SYSTEMS] + [
+    ("wtx", 256, 32, 4, 1), ("WOLA", 256, 32, 4, 1), ("CPW", 256, 32, 6, 0), ("CPwtx", 256, 10, 4, 1),
+    ("wrx", 256, 12, 2, 0), ("WOLA", 128, 32, 4, 1), ("WOLA", 512, 32, 4, 1), ("CPW", 512, 20, 6, 1),
+    ("WOLA", 1024, 32, 6, 1), ("CPwrx", 1024, 32, 2, 0)]
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k,matlab", CASES)
+@pytest.mark.parametrize("inject", [False, True])
+def test_one_frame_stage_by_stage(channels, system, n_fft, cp, k, matlab, inject):
+    S, seed, frame = 16, 11, 123456789012
+    st = W.make_structure(system, n_fft, cp)
+    rs = np.random.RandomState(n_fft + cp + k)
+    # non-trivial windows: flat level != 1 and non-RC tails, rounded to float32 on both sides
+    xt = np.concatenate(([1.03], np.sort(rs.uniform(.05, .95, st.tail_tx))[::-1])) if st.tail_tx else [1.0]
+    xr = np.concatenate(([0.97], np.sort(rs.uniform(.05, .45, st.tail_rx // 2))[::-1])) if st.tail_rx else [1.0]
+    w_tx = (W.expand_tx_window(st, xt) if st.tail_tx else np.ones(st.sym_len)).astype(np.float32)
+    w_rx = (W.expand_rx_window(st, xr) if st.tail_rx else np.ones(st.rx_win_len)).astype(np.float32)
+    h = channels[4:7].astype(np.complex64)
+    snrs = np.array([8.0, 22.0], dtype=np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 3, 2, 1, noise_before_truncate=bool(matlab), seed=seed)
+    osys = _osys(st, k, S, 21, matlab)
+    cell = 4                                           # snr index 1, channel 1
+    lab = O.gen_labels(osys, seed, cell, frame)
+    noise = O.gen_noise(osys, seed, cell, frame)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64),
+                     h[1].astype(np.complex128), float(snrs[1]), lab, noise, dump=True)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        if inject:
+            gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
+        else:
+            gc, gd = plan.dump_frame(cell, frame)
+    # integer work: bit-exact
+    assert np.array_equal(gd["labels_tx"], lab)
+    assert int(gc[1]) == int(oc[1]) == (S - 1) * n_fft * k and int(gc[3]) == int(oc[3])
+    # floating point stages
+    nconv = od["conv"].size if matlab else S * st.stride
+    assert _rel(gd["unit_noise"], noise) < 1e-5
+    assert _rel(gd["X"], od["X"]) < 1e-6
+    assert _rel(gd["tx"], od["tx"]) < STAGE_RTOL
+    assert _rel(gd["conv"][:nconv], od["conv"][:nconv]) < STAGE_RTOL
+    assert abs(float(gd["gain"][0]) / float(od["gain"][0]) - 1) < 1e-5
+    assert _rel(gd["rx"], od["rx"]) < STAGE_RTOL
+    assert _rel(gd["Y"], od["Y"]) < STAGE_RTOL
+    # decisions: identical except where the equalised point sits on a decision boundary
+    mism = gd["labels_rx"] != od["labels_rx"]
+    if mism.any():
+        a = np.sqrt(2 * (2 ** k - 1) / 3)
+        z = od["Xhat"][mism] * a
+        dist = np.minimum(np.abs(((z.real + 1) % 2) - 1), np.abs(((z.imag + 1) % 2) - 1))
+        # boundaries of the slicer sit at even integers of the scaled grid
+        edge = np.minimum(np.abs((z.real / 2) - np.round(z.real / 2)) * 2,
+                          np.abs((z.imag / 2) - np.round(z.imag / 2)) * 2)
+        assert (edge < 1e-3).all(), (int(mism.sum()), edge.max(), dist.min())
+    assert abs(int(gc[0]) - int(oc[0])) <= 2 * int(mism.sum())
+    assert abs(int(gc[2]) - int(oc[2])) <= int(mism.sum())
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k,matlab", [("wtx", 64, 16, 2, 1), ("WOLA", 256, 32, 4, 1),
+                                                      ("CPW", 256, 14, 6, 0), ("wrx", 512, 32, 4, 1)])
+def test_generate_sweep_counts_match_oracle(channels, system, n_fft, cp, k, matlab):
+    """Persistent multi-cell launch (2 window pairs x 3 SNR x 2 channels), frames from a
+    non-zero offset: counters vs the oracle's generate-mode sweep on the same Philox streams."""
+    S, seed, F, off = 16, 77, 24, 1000
+    st = W.make_structure(system, n_fft, cp)
+    w_tx = np.stack([W.tx_rc_window(st), np.full(st.sym_len, 1.0)]).astype(np.float32)
+    w_rx = np.stack([W.rx_rc_window(st), W.rx_rc_window(st)]).astype(np.float32)
+    h = channels[10:12].astype(np.complex64)
+    snrs = np.array([0.0, 14.0, 28.0], dtype=np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 2, 3, 2, noise_before_truncate=bool(matlab), seed=seed,
+                     frames_per_cell=F, frame_offset=off)
+    got = W.run_counts(cfg, w_tx, w_rx, h, snrs)
+    want = O.run(_osys(st, k, S, 21, matlab), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                 h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    assert got.shape == want.shape == (2, 3, 2, 4)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    bits = float(want[0, 0, 0, 1])
+    # fp32 vs fp64 marginal decisions only: <= 1e-4 of the bits per cell
+    assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
+    assert (np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
+    assert got[..., 0].sum() > 0
+
+
+def test_injected_sweep_counts_match_oracle(channels):
+    S, k, F = 16, 4, 3
+    st = W.make_structure("WOLA", 256, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[20:22].astype(np.complex64)
+    snrs = np.array([10.0, 30.0], dtype=np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, noise_before_truncate=True, seed=0, frames_per_cell=F)
+    osys = _osys(st, k, S, 21, True)
+    nl = O.noise_len(osys)
+    rs = np.random.RandomState(1)
+    labels = rs.randint(0, 16, size=(4, F, S, 256)).astype(np.uint8)
+    noise = (rs.randn(4, F, nl) + 1j * rs.randn(4, F, nl)).astype(np.complex64)
+    got = W.run_counts_injected(cfg, w_tx, w_rx, h, snrs, labels, noise)
+    want = np.zeros((1, 2, 2, 4), dtype=np.uint64)
+    for cell in range(4):
+        sn, ch = divmod(cell, 2)
+        for f in range(F):
+            c, _ = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64),
+                           h[ch].astype(np.complex128), float(snrs[sn]), labels[cell, f],
+                           noise[cell, f].astype(np.complex128))
+            want[0, sn, ch] += c
+    assert np.array_equal(got[..., 1], want[..., 1])
+    assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= 2).all()
+    assert (np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)) <= 2).all()
+
+
+def test_reference_ser_replay_on_gpu(golden):
+    """The reference simulator's own seeded SER (tests/golden/ser_replay.npz) reproduced by the
+    HIP path in injected mode: the reference's 16-point alphabet is the Gray grid up to scale,
+    so each drawn symbol is mapped to the label of the same constellation point."""
+    g = golden("ser_replay.npz")
+    table = O.qam_table(4) * np.sqrt(10)
+    to_gray = np.array([int(np.argmin(np.abs(table - s))) for s in SYM16], dtype=np.uint8)
+    assert np.allclose(table[to_gray], SYM16)
+    S = 16
+    for idx in (7, 8, 9):                              # the N=256 cases: wtx, WOLA, CPW(cp 10)
+        key = "case%d" % idx
+        n_fft, cp, cs, ttx, trx, rm, shift, ens, seed = [int(v) for v in g[key + "_cfg"]]
+        snr, h = g[key + "_snr"], g[key + "_h"]
+        st = W.variants.Structure(str(g[key + "_system"]), n_fft, cp, ttx, trx, cs, rm, shift)
+        B = st.stride
+        w_tx = np.stack([g[key + "_wtx"], g[key + "_wtx_rc"]]).astype(np.float32)
+        w_rx = np.stack([g[key + "_wrx"], g[key + "_wrx_rc"]]).astype(np.float32)
+        n_snr, n_ch = snr.size, h.shape[0]
+        labels = np.zeros((2, n_snr, n_ch, ens, S, n_fft), dtype=np.uint8)
+        noise = np.zeros((2, n_snr, n_ch, ens, S * B), dtype=np.complex64)
+        rs = np.random.RandomState(seed)
+        for si in range(n_snr):
+            for ci in range(n_ch):
+                for e in range(ens):
+                    lab = to_gray[rs.choice(16, size=(n_fft, S)).T]
+                    for pi in range(2):
+                        labels[pi, si, ci, e] = lab
+                        re = rs.randn(S * B); im = rs.randn(S * B)
+                        noise[pi, si, ci, e] = re + 1j * im
+        cfg = W.make_cfg(st, 4, S, h.shape[1], n_ch, n_snr, 2, noise_before_truncate=False,
+                         frames_per_cell=ens)
+        counts = W.run_counts_injected(cfg, w_tx, w_rx, h.astype(np.complex64),
+                                       snr.astype(np.float32),
+                                       labels.reshape(2 * n_snr * n_ch, ens, S, n_fft),
+                                       noise.reshape(2 * n_snr * n_ch, ens, S * B))
+        ser = counts[..., 2].sum(axis=2) / counts[..., 3].sum(axis=2)
+        syms = ens * n_ch * (S - 1) * n_fft
+        # exact up to fp32-vs-fp64 decisions on the boundary: at most 2 symbols per point
+        assert np.abs(ser[0] - g[key + "_ser_opt"]).max() <= 2.0 / syms + 1e-12, key
+        assert np.abs(ser[1] - g[key + "_ser_rc"]).max() <= 2.0 / syms + 1e-12, key
+
+
+def test_frame_ranges_add_up_bit_exactly(channels):
+    """Sharding property (what the multi-GPU path relies on): counters of [0,F) equal the sum of
+    the counters of any split of the frame range, for every launch geometry."""
+    st = W.make_structure("wtx", 256, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.linspace(-5, 50, 12).astype(np.float32)
+    cfg = W.make_cfg(st, 4, 16, 21, 1, 12, 1, seed=2)
+    with W.Plan(cfg, w_tx, w_rx, channels[:1].astype(np.complex64), snrs) as plan:
+        whole = plan.run(0, 4000)
+        parts = plan.run(0, 1) + plan.run(1, 1499) + plan.run(1500, 2500)
+        again = plan.run(0, 4000)
+    assert np.array_equal(whole, parts) and np.array_equal(whole, again)
+    ber = whole[0, :, 0, 0] / whole[0, :, 0, 1]
+    assert (np.diff(ber) <= 0).all() and (np.diff(ber[:8]) < 0).all() and ber[0] > 0.2 and ber[-1] < 1e-3
+
+
+def test_awgn_textbook_ber_full_size():
+    """Size-independent property at BASELINE scale: identity channel, rectangular windows,
+    QPSK: BER must follow Q(sqrt(snr_eff)) with the one-symbol pilot doubling the noise."""
+    from math import erfc, sqrt
+    st = W.make_structure("CP", 256, 32)
+    cfg = W.make_cfg(st, 2, 16, 1, 1, 3, 1, seed=9, frames_per_cell=20000)
+    snrs = np.array([4.0, 8.0, 12.0], dtype=np.float32)
+    counts = W.run_counts(cfg, np.ones(st.sym_len), np.ones(st.rx_win_len), np.ones((1, 1)), snrs)
+    ber = counts[0, :, 0, 0] / counts[0, :, 0, 1]
+    assert counts[0, 0, 0, 1] == 20000 * 15 * 256 * 2
+    for b, s in zip(ber, snrs):
+        # per-sample SNR s; after the N-point DFT signal and noise both scale by N; the LS pilot
+        # estimate adds an equal, independent noise term -> effective SNR ~ s/2 (plus a small
+        # ratio-distribution correction), so bracket between the two closed forms
+        lo = 0.5 * erfc(sqrt(10 ** (s / 10) / 2))            # perfect channel knowledge
+        hi = 0.5 * erfc(sqrt(10 ** (s / 10) / 2 / 4.0))
+        assert lo < b < hi, (s, b, lo, hi)
+
+
+def test_error_paths():
+    st = W.make_structure("wtx", 256, 32)
+    bad = W.make_cfg(st, 3, 16, 21, 1, 1, 1)
+    with pytest.raises(W._lib.WofdmError) as e:
+        W.run_counts(bad, np.ones(st.sym_len), np.ones(st.rx_win_len), np.ones((1, 21)), [10.0])
+    assert e.value.code == -2
+    cfg = W.make_cfg(st, 4, 16, 21, 1, 1, 1)
+    cfg.prefix_rm = 5
+    with pytest.raises(W._lib.WofdmError) as e:
+        W.run_counts(cfg, np.ones(st.sym_len), np.ones(st.rx_win_len), np.ones((1, 21)), [10.0])
+    assert e.value.code == -1
+    with pytest.raises(W._lib.WofdmError) as e:
+        W.Plan(W.make_cfg(st, 4, 16, 21, 1, 1, 1), np.ones(st.sym_len), np.ones(st.rx_win_len),
+               np.ones((1, 21)), [10.0], device=99)
+    assert e.value.code == -3
+
+
+def test_reference_operator_mirrors(channels, tmp_path):
+    """run_simulation (MATLAB signature) and wOFDMSystem.run_simulation (Python signature)."""
+    st = W.make_structure("WOLA", 256, 32)
+    ber = W.run_simulation(50, 16, 4, 256, 32, st.cs, np.diag(W.tx_rc_window(st)), channels[0], 20.0,
+                           st.tail_tx, st.tail_rx, np.diag(W.rx_rc_window(st)), st.prefix_rm,
+                           st.circ_shift, seed=3)
+    want = O.run(_osys(st, 4, 16, 21, True), W.tx_rc_window(st).astype(np.float32).astype(np.float64),
+                 W.rx_rc_window(st).astype(np.float32).astype(np.float64),
+                 channels[:1].astype(np.complex64).astype(np.complex128), [20.0], 3, 0, 50)
+    assert abs(ber - want[0, 0, 0, 0] / want[0, 0, 0, 1]) < 2e-4
+    model = W.wOFDMSystem("wtx", 256, 32, 8, 0, str(tmp_path), seed=4)
+    snr = np.arange(0, 40, 10)
+    opt, rc = model.run_simulation(channels[:3].T, np.diag(W.tx_rc_window(model.structure)),
+                                   np.diag(W.rx_rc_window(model.structure)), 20, snr, 16)
+    assert (tmp_path / "ser" / "opt_wtx_32.npy").exists() and (tmp_path / "ser" / "rc_wtx_32.npy").exists()
+    assert opt.shape == (4,) and (np.diff(opt) < 0).all()
+    # same windows on both pairs, independent data: equal within Monte-Carlo noise
+    assert np.abs(opt - rc).max() < 0.05
+    # anchors from the reference run in BASELINE.md section 2 (wtx, N=256, RC windows)
+    assert abs(opt[1] - 0.511) < 0.05 and abs(opt[2] - 0.112) < 0.03

@@ -1,0 +1,150 @@
+"""Host-side logic that needs no GPU: structure table, windows, sharding, ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import wofdm_amd as W
+from wofdm_amd import variants as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYSTEMS = ["wtx", "wrx", "WOLA", "CPW", "CPwtx", "CPwrx", "CP"]
+
+
+def test_structure_table_matches_reference(golden):
+    g = golden("structure_params.npz")
+    for system in SYSTEMS:
+        for n_fft, cp in ((64, 16), (256, 32), (256, 10)):
+            key = "%s_N%d_cp%d" % (system, n_fft, cp)
+            cs, rm, shift, ttx, trx = [int(v) for v in g[key + "_params"]]
+            st = V.make_structure(system, n_fft, cp)
+            assert (st.cs, st.prefix_rm, st.circ_shift, st.tail_tx, st.tail_rx) == (cs, rm, shift, ttx, trx)
+            assert st.stride == n_fft + trx + rm
+            if ttx:
+                assert np.allclose(V.tx_rc_window(st), g[key + "_rc_tx"], rtol=0, atol=1e-15)
+            if trx:
+                assert np.allclose(V.rx_rc_window(st), g[key + "_rc_rx"], rtol=0, atol=1e-15)
+
+
+def test_survey_table_values():
+    # SURVEY.md 3.4, N=256, mu=32: P / B / gamma
+    want = {"wtx": (296, 288, 32), "wrx": (293, 293, 27), "WOLA": (296, 288, 22), "CPW": (301, 293, 27),
+            "CPwtx": (288, 280, 24), "CPwrx": (288, 288, 22), "CP": (288, 288, 32)}
+    for system, (P, B, gam) in want.items():
+        st = V.make_structure(system, 256, 32)
+        assert (st.sym_len, st.stride, st.prefix_rm) == (P, B, gam)
+    assert np.allclose(V.rc_tail(8), [0.009607, 0.084265, 0.222215, 0.402455, 0.597545, 0.777785,
+                                      0.915735, 0.990393], atol=1e-6)
+    with pytest.raises(ValueError):
+        V.make_structure("WOLA", 256, 8)        # cp shorter than tail_rx
+    with pytest.raises(ValueError):
+        V.make_structure("ofdm", 256, 32)
+
+
+def test_tail_vector_expansion_matches_reference(golden):
+    g = golden("structure_params.npz")
+    for system in SYSTEMS:
+        st = V.make_structure(system, 64, 16)
+        if st.tail_tx:
+            assert np.array_equal(V.expand_tx_window(st, g[system + "_tailvec_tx"]), g[system + "_expanded_tx"])
+        if st.tail_rx:
+            w = V.expand_rx_window(st, g[system + "_tailvec_rx"])
+            assert np.allclose(w, g[system + "_expanded_rx"], rtol=0, atol=1e-15)
+            half = st.tail_rx // 2
+            x0 = g[system + "_tailvec_rx"][0]
+            assert np.allclose(w[:half] + w[64:64 + half], x0)      # folded samples sum to x0
+    st = V.make_structure("WOLA", 256, 32)
+    xt, xr = V.split_tail_file(st, np.arange(15.0))
+    assert xt.size == 9 and xr.size == 6
+
+
+def test_matlab_pair_plan():
+    assert [t for t, _ in V.matlab_pair_plan("wtx")] == ["opt", "rc"]
+    assert [t for t, _ in V.matlab_pair_plan("WOLA")] == ["rc", "1A", "2A", "3A", "1B", "2B", "3B"]
+    counts = np.zeros((7, 3, 2, 4), dtype=np.uint64)
+    counts[..., 1] = 100
+    counts[2, :, :, 0] = 10
+    res = W.results_from_counts("CPW", counts)
+    assert set(res) == {"berRCSNR", "berSNRStep1A", "berSNRStep2A", "berSNRStep3A", "berSNRStep1B",
+                        "berSNRStep2B", "berSNRStep3B"}
+    assert np.allclose(res["berSNRStep2A"], 0.1) and np.allclose(res["berRCSNR"], 0)
+
+
+def test_save_ber_results_uses_reference_variable_names(tmp_path):
+    from scipy.io import loadmat
+    res = {"berSNR": np.linspace(.5, .1, 5), "berRCSNR": np.linspace(.5, .2, 5)}
+    W.save_ber_results(str(tmp_path), "wtx", 32, res)
+    a = loadmat(str(tmp_path / "optimized_ber_wtx_32CP.mat"))
+    b = loadmat(str(tmp_path / "rc_ber_wtx_32CP.mat"))
+    assert a["berSNR"].shape == (5, 1) and b["berRCSNR"].shape == (5, 1)
+
+
+def test_frame_shard_partitions_exactly():
+    from wofdm_amd.distributed import frame_shard
+    for total in (0, 1, 7, 62500, 10 ** 6 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [frame_shard(total, r, world, frame_offset=17) for r in range(world)]
+            assert spans[0][0] == 17 and sum(c for _, c in spans) == total
+            for (o1, c1), (o2, _) in zip(spans, spans[1:]):
+                assert o1 + c1 == o2
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        frame_shard(10, 2, 2)
+
+
+def test_cfg_struct_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "wofdm.h")).read()
+    body = hdr[hdr.index("typedef struct wofdm_cfg {"):hdr.index("} wofdm_cfg;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:int32_t|uint64_t)\s+([^;]+);", body)
+    fields = [n.strip() for grp in names for n in grp.split(",")]
+    assert fields == [f for f, _ in W._lib.Cfg._fields_]
+    assert C.sizeof(W._lib.Cfg) == 14 * 4 + 3 * 8
+    dbody = hdr[hdr.index("typedef struct wofdm_dump {"):hdr.index("} wofdm_dump;")]
+    dbody = re.sub(r"/\*.*?\*/", "", dbody, flags=re.S)
+    dnames = re.findall(r"\*\s*(\w+);", dbody)
+    assert dnames == [f for f, _ in W._lib.Dump._fields_]
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "wofdm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wofdm_\w+)\s*\(", hdr))
+    assert declared == set(W._lib.EXPORTS)
+    lib = W._lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wofdm_version() == 1
+    cfg = W.make_cfg(V.make_structure("wtx", 256, 32), 4, 16, 21, 1, 12, 1)
+    assert lib.wofdm_noise_len(C.byref(cfg)) == 8 + 16 * 288 + 20
+    cfg.noise_before_truncate = 0
+    assert lib.wofdm_noise_len(C.byref(cfg)) == 16 * 288
+    cfg.n_fft = 100
+    assert lib.wofdm_noise_len(C.byref(cfg)) == -2
+    assert b"n_fft" in lib.wofdm_last_error()
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU every compute entry point must fail loudly."""
+    lib = W._lib.load()
+    if lib.wofdm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    st = V.make_structure("wtx", 64, 16)
+    cfg = W.make_cfg(st, 2, 16, 21, 1, 1, 1, frames_per_cell=1)
+    with pytest.raises(W._lib.WofdmError) as e:
+        W.run_counts(cfg, V.tx_rc_window(st), V.rx_rc_window(st), np.ones((1, 21)), [10.0])
+    assert e.value.code == -3
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package, include/ or the root
+    shim may mention it."""
+    pkg = os.path.join(ROOT, "w-ofdm-optimization_amd")
+    files = [os.path.join(ROOT, "wofdm_amd.py")]
+    for d, _, fs in os.walk(pkg):
+        files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile"))]
+    for f in files:
+        txt = open(f).read()
+        assert "oracle" not in txt.lower(), f

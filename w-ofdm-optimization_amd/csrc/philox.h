@@ -1,5 +1,5 @@
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
-// SC'11) and the stream layout shared by the HIP kernels and the CPU oracle.
+// SC'11) and the random-stream layout of the HIP kernels (DESIGN.md "RNG").
 //
 //   key     = (seed lo, seed hi)
 //   counter = (block, frame lo, frame hi, stream << 28 | cell)

@@ -192,7 +192,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
     const double a = std::sqrt(2.0 * ((1 << g.k) - 1) / 3.0);
     kp.qam_scale = (float)(1.0 / a); kp.qam_inv = (float)a;
-    kp.lds = wofdm_make_layout(g.N, g.S, g.k, g.P, g.B, g.beta, g.delta);
+    kp.lds = wofdm_make_layout(g.N, g.S, g.P, g.B, g.beta, g.delta);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
     hipDeviceProp_t prop;

@@ -21,7 +21,6 @@ struct wofdm_lds_layout {
     int g_len;      // float2: N
     int wtx_len;    // float : P
     int wrx_len;    // float : N + delta
-    int bits_len;   // u32   : S * bits words per symbol
     int sums_len;   // float : 2 * S
     size_t bytes;
 };
@@ -48,8 +47,7 @@ struct wofdm_kparams {
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 static inline int wofdm_rb(int n_fft) { return n_fft / 64 + 1; }   // outputs per lane in the FIR
 
-static inline wofdm_lds_layout wofdm_make_layout(int N, int S, int k, int P, int B, int beta,
-                                                 int delta)
+static inline wofdm_lds_layout wofdm_make_layout(int N, int S, int P, int B, int beta, int delta)
 {
     wofdm_lds_layout l;
     const int T = beta + S * B;
@@ -60,10 +58,9 @@ static inline wofdm_lds_layout wofdm_make_layout(int N, int S, int k, int P, int
     l.g_len = N;
     l.wtx_len = up(P, 4);
     l.wrx_len = up(N + delta, 4);
-    l.bits_len = up(S * (N * wofdm_kslot(k) / 32), 4);
     l.sums_len = up(2 * S, 4);
     l.bytes = (size_t)8 * (l.fbuf_len + l.tail_len + l.tw_len + l.g_len)
-            + (size_t)4 * (l.wtx_len + l.wrx_len + l.bits_len + l.sums_len);
+            + (size_t)4 * (l.wtx_len + l.wrx_len + l.sums_len);
     return l;
 }
 

@@ -267,8 +267,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     float2 *G = tw + p.lds.tw_len;
     float *wtx = reinterpret_cast<float *>(G + p.lds.g_len);
     float *wrx = wtx + p.lds.wtx_len;
-    uint32_t *bitsw = reinterpret_cast<uint32_t *>(wrx + p.lds.wrx_len);
-    float *sums = reinterpret_cast<float *>(bitsw + p.lds.bits_len);
+    float *sums = wrx + p.lds.wrx_len;
 
     float2 *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
 
@@ -357,8 +356,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
         float2 v[BPL][4];
         uint32_t lab[BPL];
+        // the symbol's Philox words are staged in the wave's own (still unused) frame slice
+        uint32_t *bw = reinterpret_cast<uint32_t *>(fb);
         if (!INJECT) {
-            uint32_t *bw = bitsw + s * (bps * 4);
             if (lane < bps) {
                 const philox_out o = philox4x32_10((uint32_t)(s * bps + lane), f_lo, f_hi,
                                                    (WOFDM_STREAM_BITS << 28) | cell,
@@ -381,7 +381,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         L = p.labels[(inj * S + s) * N + n] & lmask;
                     } else {
                         const uint32_t bit = (uint32_t)n * (uint32_t)ks;
-                        L = (bitsw[s * (bps * 4) + (bit >> 5)] >> (bit & 31u)) & lmask;
+                        L = (bw[bit >> 5] >> (bit & 31u)) & lmask;
                     }
                     lab[q] |= L << (8 * r);
                     const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
