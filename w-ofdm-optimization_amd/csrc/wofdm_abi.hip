@@ -64,6 +64,8 @@ int check_cfg(const wofdm_cfg *c, geom *g)
     if (g->B != N + g->delta + g->gamma)
         return fail(WOFDM_E_INVALID, "n_fft+cp+cs-tail_tx (%d) != n_fft+tail_rx+prefix_rm (%d)",
                     g->B, N + g->delta + g->gamma);
+    if (g->mu + g->rho > 128 || g->beta > 16 || g->delta > 64)
+        return fail(WOFDM_E_UNSUPPORTED, "kernel limits: cp+cs <= 128, tail_tx <= 16, tail_rx <= 64");
     if (g->B > 64 * wofdm_rb(N))
         return fail(WOFDM_E_UNSUPPORTED, "cp+cs-tail_tx=%d exceeds the 64 samples the kernel's "
                     "FIR tiling allows", g->B - N);
@@ -100,7 +102,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     if (force_grid > 0) grid = (uint64_t)force_grid;
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                            dim3(64u * (unsigned)pl->g.S), args, kp.lds.bytes, stream));
+                            dim3(64u * (unsigned)pl->g.S), args, kp.lds_bytes, stream));
     return WOFDM_OK;
 }
 
@@ -190,31 +192,31 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     kp.gamma = g.gamma; kp.kappa = g.kappa; kp.L = g.L; kp.P = g.P; kp.B = g.B; kp.T = g.T;
     kp.NL = g.NL; kp.n_snr = cfg->n_snr; kp.n_ch = cfg->n_channels;
     kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
-    const double a = std::sqrt(2.0 * ((1 << g.k) - 1) / 3.0);
-    kp.qam_scale = (float)(1.0 / a); kp.qam_inv = (float)a;
-    kp.lds = wofdm_make_layout(g.N, g.S, g.P, g.B, g.beta, g.delta);
+    kp.fbuf_len = wofdm_fbuf_len(g.N, g.T);
+    kp.lds_bytes = wofdm_lds_bytes(g.N, g.T);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
     hipDeviceProp_t prop;
     PLAN_TRY(hipGetDeviceProperties(&prop, device));
     pl->cus = prop.multiProcessorCount;
-    if (kp.lds.bytes > (size_t)prop.sharedMemPerBlock && kp.lds.bytes > 160u * 1024u) {
+    if (kp.lds_bytes > 160u * 1024u) {
         wofdm_plan_destroy(pl);
-        return fail(WOFDM_E_UNSUPPORTED, "frame needs %zu bytes of LDS", kp.lds.bytes);
+        return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)",
+                    kp.lds_bytes);
     }
     for (int m = 0; m < 4; ++m) {
-        pl->fn[m] = wofdm_select_kernel(g.N, m);
+        pl->fn[m] = wofdm_select_kernel(g.N, g.k, m);
         if (!pl->fn[m]) continue;
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[m]),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kp.lds.bytes));
+                                     (int)kp.lds_bytes));
     }
     int occ = 0;
     PLAN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S, kp.lds.bytes));
+        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S, kp.lds_bytes));
     if (occ < 1) {
         wofdm_plan_destroy(pl);
-        return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %zu bytes)", kp.lds.bytes);
+        return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", kp.lds_bytes);
     }
     pl->occ = occ;
 #undef PLAN_TRY
@@ -240,7 +242,7 @@ int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
     info[0] = pl->g.S;
-    info[1] = (int32_t)pl->base.lds.bytes;
+    info[1] = (int32_t)pl->base.lds_bytes;
     info[2] = pl->cus * pl->occ;
     info[3] = pl->occ;
     info[4] = pl->cus;

@@ -13,16 +13,23 @@ struct wofdm_kdump {          // device pointers, all may be null
     float2  *unit_noise;
 };
 
-// LDS carve (float2 units first, then floats); must match the kernel.
-struct wofdm_lds_layout {
-    int fbuf_len;   // float2: WOFDM_LT-1 | T + L - 1 ... | pad
-    int tail_len;   // float2: S * beta
-    int tw_len;     // float2: N
-    int g_len;      // float2: N
-    int wtx_len;    // float : P
-    int wrx_len;    // float : N + delta
-    int sums_len;   // float : 2 * S
-    size_t bytes;
+// LDS carve: fixed-size regions first (compile-time offsets), the frame buffer last.
+//   tw    float2[N]          twiddles exp(-2 pi i m / N)
+//   g     float2[N]          pilot equaliser X0/Y0
+//   sums  float [32]         per-wave signal / noise power partials
+//   wtx   float [N + 128]    Tx window / N      (needs cp + cs <= 128)
+//   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)
+//   tail  float2[16][16]     fall tails         (needs tail_tx <= 16)
+//   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
+template <int N> struct wofdm_lds {
+    static constexpr int TAIL_MAX = 16, CPCS_MAX = 128, TAILRX_MAX = 64;
+    static constexpr int off_tw = 0;
+    static constexpr int off_g = off_tw + 8 * N;
+    static constexpr int off_sums = off_g + 8 * N;
+    static constexpr int off_wtx = off_sums + 4 * 32;
+    static constexpr int off_wrx = off_wtx + 4 * (N + CPCS_MAX);
+    static constexpr int off_tail = off_wrx + 4 * (N + TAILRX_MAX);
+    static constexpr int off_fbuf = off_tail + 8 * 16 * TAIL_MAX;
 };
 
 struct wofdm_kparams {
@@ -34,8 +41,8 @@ struct wofdm_kparams {
     uint32_t n_cells;       // cells covered by this launch, starting at first_cell
     uint32_t first_cell;
     uint32_t inject_base_cell;   // injected arrays are indexed from this cell
-    float qam_scale, qam_inv;    // 1/sqrt(2(M-1)/3) and its reciprocal
-    wofdm_lds_layout lds;
+    int fbuf_len;                // float2 entries of the frame buffer
+    unsigned lds_bytes;
     uint64_t frames_per_cell, frame_offset;
     uint32_t seed_lo, seed_hi;
     unsigned long long *counts;   // [cells][4]
@@ -47,21 +54,14 @@ struct wofdm_kparams {
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 static inline int wofdm_rb(int n_fft) { return n_fft / 64 + 1; }   // outputs per lane in the FIR
 
-static inline wofdm_lds_layout wofdm_make_layout(int N, int S, int P, int B, int beta, int delta)
+static inline int wofdm_fbuf_len(int N, int T)
 {
-    wofdm_lds_layout l;
-    const int T = beta + S * B;
-    auto up = [](int v, int a) { return (v + a - 1) / a * a; };
-    l.fbuf_len = up((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N) + 8, 2);
-    l.tail_len = up(S * (beta > 0 ? beta : 1), 2);
-    l.tw_len = N;
-    l.g_len = N;
-    l.wtx_len = up(P, 4);
-    l.wrx_len = up(N + delta, 4);
-    l.sums_len = up(2 * S, 4);
-    l.bytes = (size_t)8 * (l.fbuf_len + l.tail_len + l.tw_len + l.g_len)
-            + (size_t)4 * (l.wtx_len + l.wrx_len + l.sums_len);
-    return l;
+    return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N) + 8 + 1) / 2 * 2;
+}
+static inline unsigned wofdm_lds_bytes(int N, int T)
+{
+    const int fixed = 8 * N + 8 * N + 4 * 32 + 4 * (N + 128) + 4 * (N + 64) + 8 * 16 * 16;
+    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T));
 }
 
 // kernel registry (wofdm_kernel.hip)
@@ -70,5 +70,5 @@ static inline wofdm_lds_layout wofdm_make_layout(int N, int S, int P, int B, int
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
                                 const float *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int mode);
+wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int mode);
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);

@@ -73,7 +73,7 @@ __device__ __forceinline__ void fft_first(float2 (&v)[geo<N>::BPL][4], float2 *f
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (j < geo<N>::NQ) {
+        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
             radix4<DIR>(v[q]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) fb[4 * j + r] = v[q][r];
@@ -89,7 +89,7 @@ __device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (j < geo<N>::NQ) {
+        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
             const int k = j & (NS - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[q][r] = fb[j + r * geo<N>::NQ];
@@ -102,7 +102,7 @@ __device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (j < geo<N>::NQ) {
+        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
             const int k = j & (NS - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) fb[((j - k) << 2) + k + r * NS] = u[q][r];
@@ -146,7 +146,7 @@ __device__ __forceinline__ void fft_last(float2 (&v)[geo<N>::BPL][4], const floa
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (j < geo<N>::NQ) {
+        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = fb[j + r * geo<N>::NQ];
 #pragma unroll
@@ -231,6 +231,15 @@ __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b)
     return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
 }
 
+// One block of stream `stream` of (seed, cell, frame).  The key words are made opaque so the
+// ten round keys are re-derived with scalar adds per call instead of occupying 20 SGPRs.
+__device__ __forceinline__ philox_out stream_block(uint32_t block, uint32_t f_lo, uint32_t f_hi,
+                                                   uint32_t stream_cell, uint32_t k0, uint32_t k1)
+{
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    return philox4x32_10(block, f_lo, f_hi, stream_cell, k0, k1);
+}
+
 __device__ __forceinline__ float wave_sum(float x)
 {
 #pragma unroll
@@ -244,7 +253,7 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
     return x;
 }
 
-template <int N, bool INJECT, bool DUMP>
+template <int N, int K, bool INJECT, bool DUMP>
 __global__ void __launch_bounds__(1024)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h,
@@ -259,19 +268,22 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     const int s = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = lane0;
     const int S = p.S, B = p.B, beta = p.beta, mu = p.mu, rho = p.rho, delta = p.delta;
-    const int gam = p.gamma, kap = p.kappa, NL = p.NL, k = p.k;
+    const int gam = p.gamma, kap = p.kappa, NL = p.NL;
 
-    float2 *fbuf = reinterpret_cast<float2 *>(smem);
-    float2 *tailb = fbuf + p.lds.fbuf_len;
-    float2 *tw = tailb + p.lds.tail_len;
-    float2 *G = tw + p.lds.tw_len;
-    float *wtx = reinterpret_cast<float *>(G + p.lds.g_len);
-    float *wrx = wtx + p.lds.wtx_len;
-    float *sums = wrx + p.lds.wrx_len;
+    // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
+    // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
+    using L = wofdm_lds<N>;
+    float2 *tw = reinterpret_cast<float2 *>(smem + L::off_tw);
+    float2 *G = reinterpret_cast<float2 *>(smem + L::off_g);
+    float *sums = reinterpret_cast<float *>(smem + L::off_sums);
+    float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
+    float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
+    float2 *tailb = reinterpret_cast<float2 *>(smem + L::off_tail);
+    float2 *fbuf = reinterpret_cast<float2 *>(smem + L::off_fbuf);
 
     float2 *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
 
-    for (int i = tid; i < p.lds.fbuf_len; i += blockDim.x) fbuf[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < p.fbuf_len; i += blockDim.x) fbuf[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < N; i += blockDim.x) {
         float sv, cv;
         sincospif(-2.0f * (float)i / (float)N, &sv, &cv);
@@ -280,11 +292,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     __syncthreads();
 
     // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
-    const int half = k >> 1, m1 = (1 << half) - 1;
-    const uint32_t lmask = (1u << k) - 1u;
-    const float qscale = p.qam_scale, qinv = p.qam_inv;
-    const int ks = k == 6 ? 8 : k;
-    const int bps = N * ks / 128;                 // Philox blocks of data bits per symbol
+    constexpr int k = K, half = K >> 1, m1 = (1 << half) - 1;
+    constexpr uint32_t lmask = (1u << K) - 1u;
+    constexpr float qinv = K == 2 ? 1.4142135623730951f : (K == 4 ? 3.1622776601683795f
+                                                                   : 6.4807406984078604f);
+    constexpr float qscale = 1.0f / qinv;
+    constexpr int ks = K == 6 ? 8 : K;
+    constexpr int bps = N * ks / 128;             // Philox blocks of data bits per symbol
 
     // Work items (cell, frame) are walked with scalar adds/compares only: a 64-bit divide would
     // push the (wave-uniform) loop state into VGPRs and turn every per-cell constant into a
@@ -307,6 +321,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     };
     while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
 
+    const uint32_t seed_lo = __builtin_amdgcn_readfirstlane(p.seed_lo);
+    const uint32_t seed_hi = __builtin_amdgcn_readfirstlane(p.seed_hi);
     uint32_t cur_cell = 0xFFFFFFFFu;
     int cur_pair = -1;
     uint32_t bit_err = 0, sym_err = 0, nfr = 0;
@@ -345,9 +361,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // of every stage is hoisted out of the frame loop and the kernel spills ~1500 VGPRs.
         lane = lane0;
         asm volatile("" : "+v"(lane));
-        int ch_now = __builtin_amdgcn_readfirstlane(ch);   // same trick for the scalar tap loads
-        asm volatile("" : "+s"(ch_now));
-        const float2 *__restrict__ taps = g_h + ch_now * LT;
         const uint64_t frame = p.frame_offset + fidx;
         const uint32_t f_lo = (uint32_t)frame, f_hi = (uint32_t)(frame >> 32);
         const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
@@ -360,9 +373,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         uint32_t *bw = reinterpret_cast<uint32_t *>(fb);
         if (!INJECT) {
             if (lane < bps) {
-                const philox_out o = philox4x32_10((uint32_t)(s * bps + lane), f_lo, f_hi,
-                                                   (WOFDM_STREAM_BITS << 28) | cell,
-                                                   p.seed_lo, p.seed_hi);
+                const philox_out o = stream_block((uint32_t)(s * bps + lane), f_lo, f_hi,
+                                                  (WOFDM_STREAM_BITS << 28) | cell, seed_lo, seed_hi);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bw[4 * lane + i] = o.w[i];
             }
@@ -372,7 +384,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         for (int q = 0; q < BPL; ++q) {
             const int j = lane + 64 * q;
             lab[q] = 0;
-            if (j < NQ) {
+            if (NQ >= 64 * BPL || j < NQ) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = j + r * NQ;
@@ -404,7 +416,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
         for (int q = 0; q < BPL; ++q) {
             const int j = lane + 64 * q;
-            if (j < NQ) {
+            if (NQ >= 64 * BPL || j < NQ) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = j + r * NQ;
@@ -413,7 +425,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         const float w = wtx[i];
                         const float2 val = make_float2(w * x.x, w * x.y);
                         if (i < B || s == S - 1) fb[i] = val;
-                        else tailb[s * beta + (i - B)] = val;
+                        else tailb[s * L::TAIL_MAX + (i - B)] = val;
                     };
                     put(t + mu);
                     if (t >= N - mu) put(t + mu - N);
@@ -424,7 +436,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         __syncthreads();                                                     // ---- barrier 1
 
         // ------------------------------------------------------------ B: overlap-add, FIR, noise
-        if (s > 0 && lane < beta) fb[lane] = cadd(fb[lane], tailb[(s - 1) * beta + lane]);
+        if (s > 0 && lane < beta) fb[lane] = cadd(fb[lane], tailb[(s - 1) * L::TAIL_MAX + lane]);
         wave_sync();
         if (DUMP) {
             __syncthreads();
@@ -448,6 +460,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             if (c < ntc) { j0 = S * B + c * RB; cnt = min(RB, tail_total - c * RB); }
         }
 
+        // The tap pointer is made opaque HERE so that the 42 scalar tap loads are issued after
+        // barrier 1 and die with the FIR; hoisted to the loop top they squeeze every other
+        // scalar out of the SGPR file (v_readlane traffic).
+        int ch_now = __builtin_amdgcn_readfirstlane(ch);
+        asm volatile("" : "+s"(ch_now));
+        const float2 *__restrict__ taps = g_h + ch_now * LT;
         float2 acc[RB], nz[RB];
         fir_lane<RB>(fbuf + j0, taps, acc);        // fbuf + (LT-1) + j0 - (LT-1)
 
@@ -462,9 +480,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const uint32_t b0 = (uint32_t)j0 >> 1;
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
-                    const philox_out o = philox4x32_10(b0 + b, f_lo, f_hi,
-                                                       (WOFDM_STREAM_NOISE << 28) | cell,
-                                                       p.seed_lo, p.seed_hi);
+                    const philox_out o = stream_block(b0 + b, f_lo, f_hi,
+                                                      (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
                     cand[2 * b] = box_muller(o.w[0], o.w[1]);
                     cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
                 }
@@ -506,9 +523,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (INJECT) {
                     nn = p.unit_noise[inj * NL + j];
                 } else {
-                    const philox_out o = philox4x32_10((uint32_t)j >> 1, f_lo, f_hi,
-                                                       (WOFDM_STREAM_NOISE << 28) | cell,
-                                                       p.seed_lo, p.seed_hi);
+                    const philox_out o = stream_block((uint32_t)j >> 1, f_lo, f_hi,
+                                                      (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
                     nn = (j & 1) ? box_muller(o.w[2], o.w[3]) : box_muller(o.w[0], o.w[1]);
                 }
                 ps += c.x * c.x + c.y * c.y;
@@ -526,7 +542,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
         float Ps = 0.f, Pn = 0.f;
         for (int w = 0; w < S; ++w) { Ps += sums[w]; Pn += sums[S + w]; }
-        const float g = sqrtf(Ps * nlin / Pn);      // lengths cancel (m:289-292)
+        const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         if (is_main) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -546,7 +562,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
         for (int q = 0; q < BPL; ++q) {
             const int j = lane + 64 * q;
-            if (j < NQ) {
+            if (NQ >= 64 * BPL || j < NQ) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = j + r * NQ;
@@ -570,7 +586,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
-                if (j < NQ)
+                if (NQ >= 64 * BPL || j < NQ)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p.dump.Y[s * N + j + r * NQ] = v[q][r];
             }
@@ -580,7 +596,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
-                if (j < NQ) {
+                if (NQ >= 64 * BPL || j < NQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const uint32_t L = (lab[q] >> (8 * r)) & 0xFFu;
@@ -590,7 +606,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         const float2 x0 = make_float2((float)(2 * li - m1) * qscale,
                                                       (float)(m1 - 2 * lq) * qscale);
                         const float2 y0 = v[q][r];
-                        const float inv = 1.0f / (y0.x * y0.x + y0.y * y0.y);
+                        const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
                         G[j + r * NQ] = make_float2((x0.x * y0.x + x0.y * y0.y) * inv,
                                                     (x0.y * y0.x - x0.x * y0.y) * inv);
                     }
@@ -604,7 +620,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
-                if (j < NQ) {
+                if (NQ >= 64 * BPL || j < NQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = j + r * NQ;
@@ -641,30 +657,44 @@ __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
     }
 }
 
-template <int N> wofdm_kernel_fn pick(int mode)
+template <int N, int K> wofdm_kernel_fn pick_mode(int mode)
 {
     switch (mode) {
-    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, false, false>;
-    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, true, false>;
-    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, false, true>;
-    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, true, true>;
+    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, K, false, false>;
+    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, K, true, false>;
+    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, K, false, true>;
+    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, K, true, true>;
+    }
+    return nullptr;
+}
+
+template <int N> wofdm_kernel_fn pick(int k, int mode)
+{
+    switch (k) {
+#ifdef WOFDM_ONLY_K
+    case WOFDM_ONLY_K: return pick_mode<N, WOFDM_ONLY_K>(mode);
+#else
+    case 2: return pick_mode<N, 2>(mode);
+    case 4: return pick_mode<N, 4>(mode);
+    case 6: return pick_mode<N, 6>(mode);
+#endif
     }
     return nullptr;
 }
 
 }  // namespace
 
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int mode)
+wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int mode)
 {
     switch (n_fft) {
 #ifdef WOFDM_ONLY_N        // developer builds: one DFT length, faster compile / readable ISA
-    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(mode);
+    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(bits_per_sc, mode);
 #else
-    case 64: return pick<64>(mode);
-    case 128: return pick<128>(mode);
-    case 256: return pick<256>(mode);
-    case 512: return pick<512>(mode);
-    case 1024: return pick<1024>(mode);
+    case 64: return pick<64>(bits_per_sc, mode);
+    case 128: return pick<128>(bits_per_sc, mode);
+    case 256: return pick<256>(bits_per_sc, mode);
+    case 512: return pick<512>(bits_per_sc, mode);
+    case 1024: return pick<1024>(bits_per_sc, mode);
 #endif
     }
     return nullptr;
