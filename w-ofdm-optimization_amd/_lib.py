@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwofdm_hip.so")
+# WOFDM_LIB: developer override for A/B builds of the same ABI (never a different backend)
+LIB_PATH = os.environ.get("WOFDM_LIB", os.path.join(_HERE, "libwofdm_hip.so"))
 _LIB = None
 
 WOFDM_OK = 0

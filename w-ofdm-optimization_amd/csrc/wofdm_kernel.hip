@@ -23,12 +23,19 @@
 #include "wofdm_kernel.h"
 #include "philox.h"
 
+#ifndef WOFDM_MIN_WAVES_PER_SIMD
+#define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
+#endif
+
 namespace {
 
-__device__ __forceinline__ float uniform_f(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-}
+// Complex samples are 2-wide float vectors: gfx950 issues one wave64 VALU instruction per
+// ~4 cycles per SIMD whether it is v_fma_f32 or v_pk_fma_f32 (tools/ubench/valu_rate.hip:
+// 4.5 vs 5.1 cycles), so the fp32 peak is only reachable with packed math, and complex
+// arithmetic packs naturally as (re, im).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -38,42 +45,83 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// a * w  (2 packed instructions; swizzle and sign live in the VOP3P modifiers)
+__device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-// tw[] holds exp(-2 pi i m / N): forward DFT multiplies by it, inverse by its conjugate
-template <int DIR> __device__ __forceinline__ float2 twid(float2 a, float2 w)
+// a * conj(w)
+__device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
 {
-    if (DIR < 0) return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
-    return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a + (-i) d = (a.x + d.y, a.y - d.x)   and   a + (+i) d = (a.x - d.y, a.y + d.x)
+__device__ __forceinline__ v2f add_mi(v2f a, v2f d)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ v2f add_pi(v2f a, v2f d)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+// tw tables hold exp(-2 pi i ...): the forward DFT multiplies by them, the inverse by the conjugate
+template <int DIR> __device__ __forceinline__ v2f twid(v2f a, v2f w)
+{
+    return DIR < 0 ? cmul(a, w) : cmul_conj(a, w);
 }
 
-template <int DIR> __device__ __forceinline__ void radix4(float2 (&u)[4])
+template <int DIR> __device__ __forceinline__ void radix4(v2f (&u)[4])
 {
-    const float2 a0 = cadd(u[0], u[2]), a1 = csub(u[0], u[2]);
-    const float2 a2 = cadd(u[1], u[3]), d = csub(u[1], u[3]);
-    const float2 a3 = DIR < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-    u[0] = cadd(a0, a2); u[1] = cadd(a1, a3); u[2] = csub(a0, a2); u[3] = csub(a1, a3);
+    const v2f a0 = u[0] + u[2], a1 = u[0] - u[2];
+    const v2f a2 = u[1] + u[3], d = u[1] - u[3];
+    u[0] = a0 + a2;
+    u[2] = a0 - a2;
+    u[1] = DIR < 0 ? add_mi(a1, d) : add_pi(a1, d);      // a1 + (-+ i) d
+    u[3] = DIR < 0 ? add_pi(a1, d) : add_mi(a1, d);      // a1 - (-+ i) d
 }
 
 template <int N> struct geo {
     static constexpr int NQ = N / 4;                 // radix-4 butterflies per stage
     static constexpr int BPL = (NQ + 63) / 64;       // ... per lane
     static constexpr int RB = N / 64 + 1;            // FIR outputs per lane
+    static constexpr bool FULL = NQ >= 64 * BPL;     // every lane owns BPL butterflies
+    // Twiddle tables, one per stage after the first, laid out [k][r-1] so that the three
+    // factors of a butterfly are adjacent and lanes hit distinct banks:
+    //   radix-4 stage NS: 3*NS entries exp(-2 pi i r k / (4 NS));  radix-2 stage NS: NS entries.
+    static constexpr int tw_off(int stage_ns)
+    {
+        // stages in execution order for this N (after the twiddle-free first stage)
+        int off = 0, ns = 4;
+        while (ns < stage_ns) {
+            const bool r2 = (N == 128 && ns == 4) || (N == 512 && ns == 16);
+            off += r2 ? ns : 3 * ns;
+            ns *= r2 ? 2 : 4;
+        }
+        return off;
+    }
 };
 
 // Stockham autosort stages on the wave's LDS slice fb[0..N).  Lane data v[q][r] always means
 // element (lane + 64 q) + r N/4, both as the first stage's input and the last stage's output.
 template <int N, int DIR>
-__device__ __forceinline__ void fft_first(float2 (&v)[geo<N>::BPL][4], float2 *fb, int lane)
+__device__ __forceinline__ void fft_first(v2f (&v)[geo<N>::BPL][4], v2f *fb, int lane)
 {
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
+        if (geo<N>::FULL || j < geo<N>::NQ) {
             radix4<DIR>(v[q]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) fb[4 * j + r] = v[q][r];
@@ -83,18 +131,19 @@ __device__ __forceinline__ void fft_first(float2 (&v)[geo<N>::BPL][4], float2 *f
 }
 
 template <int N, int NS, int DIR>
-__device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
+__device__ __forceinline__ void fft_mid4(v2f *fb, const v2f *tw, int lane)
 {
-    float2 u[geo<N>::BPL][4];
+    v2f u[geo<N>::BPL][4];
+    const v2f *t = tw + geo<N>::tw_off(NS);
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
+        if (geo<N>::FULL || j < geo<N>::NQ) {
             const int k = j & (NS - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[q][r] = fb[j + r * geo<N>::NQ];
 #pragma unroll
-            for (int r = 1; r < 4; ++r) u[q][r] = twid<DIR>(u[q][r], tw[r * k * (N / (4 * NS))]);
+            for (int r = 1; r < 4; ++r) u[q][r] = twid<DIR>(u[q][r], t[3 * k + r - 1]);
             radix4<DIR>(u[q]);
         }
     }
@@ -102,7 +151,7 @@ __device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
+        if (geo<N>::FULL || j < geo<N>::NQ) {
             const int k = j & (NS - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) fb[((j - k) << 2) + k + r * NS] = u[q][r];
@@ -112,18 +161,19 @@ __device__ __forceinline__ void fft_mid4(float2 *fb, const float2 *tw, int lane)
 }
 
 template <int N, int NS, int DIR>
-__device__ __forceinline__ void fft_mid2(float2 *fb, const float2 *tw, int lane)
+__device__ __forceinline__ void fft_mid2(v2f *fb, const v2f *tw, int lane)
 {
     constexpr int NB = N / 2, PER = (NB + 63) / 64;
-    float2 y0[PER], y1[PER];
+    v2f y0[PER], y1[PER];
+    const v2f *t = tw + geo<N>::tw_off(NS);
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int j = lane + 64 * q;
         if (j < NB) {
             const int k = j & (NS - 1);
-            const float2 a = fb[j];
-            const float2 b = twid<DIR>(fb[j + NB], tw[k * (N / (2 * NS))]);
-            y0[q] = cadd(a, b); y1[q] = csub(a, b);
+            const v2f a = fb[j];
+            const v2f b = twid<DIR>(fb[j + NB], t[k]);
+            y0[q] = a + b; y1[q] = a - b;
         }
     }
     wave_sync();
@@ -140,17 +190,18 @@ __device__ __forceinline__ void fft_mid2(float2 *fb, const float2 *tw, int lane)
 }
 
 template <int N, int DIR>
-__device__ __forceinline__ void fft_last(float2 (&v)[geo<N>::BPL][4], const float2 *fb,
-                                         const float2 *tw, int lane)
+__device__ __forceinline__ void fft_last(v2f (&v)[geo<N>::BPL][4], const v2f *fb,
+                                         const v2f *tw, int lane)
 {
+    const v2f *t = tw + geo<N>::tw_off(geo<N>::NQ);
 #pragma unroll
     for (int q = 0; q < geo<N>::BPL; ++q) {
         const int j = lane + 64 * q;
-        if (geo<N>::NQ >= 64 * geo<N>::BPL || j < geo<N>::NQ) {
+        if (geo<N>::FULL || j < geo<N>::NQ) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = fb[j + r * geo<N>::NQ];
 #pragma unroll
-            for (int r = 1; r < 4; ++r) v[q][r] = twid<DIR>(v[q][r], tw[r * j]);
+            for (int r = 1; r < 4; ++r) v[q][r] = twid<DIR>(v[q][r], t[3 * j + r - 1]);
             radix4<DIR>(v[q]);
         }
     }
@@ -159,8 +210,7 @@ __device__ __forceinline__ void fft_last(float2 (&v)[geo<N>::BPL][4], const floa
 
 // registers -> (LDS stages) -> registers, natural order in and out
 template <int N, int DIR>
-__device__ __forceinline__ void fft_wave(float2 (&v)[geo<N>::BPL][4], float2 *fb, const float2 *tw,
-                                         int lane)
+__device__ __forceinline__ void fft_wave(v2f (&v)[geo<N>::BPL][4], v2f *fb, const v2f *tw, int lane)
 {
     fft_first<N, DIR>(v, fb, lane);
     if constexpr (N == 64) {
@@ -184,36 +234,51 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[geo<N>::BPL][4], float2 *fb
     fft_last<N, DIR>(v, fb, tw, lane);
 }
 
+// Fill the per-stage twiddle tables (once per workgroup).
+template <int N> __device__ __forceinline__ void fill_twiddles(v2f *tw, int tid, int nthreads)
+{
+    int off = 0, ns = 4;
+    while (ns <= N / 4) {
+        const bool r2 = (N == 128 && ns == 4) || (N == 512 && ns == 16);
+        const int cnt = r2 ? ns : 3 * ns;
+        for (int i = tid; i < cnt; i += nthreads) {
+            const int k = r2 ? i : i / 3, r = r2 ? 1 : 1 + i % 3;
+            float sv, cv;
+            sincospif(-2.0f * (float)(r * k) / (float)((r2 ? 2 : 4) * ns), &sv, &cv);
+            tw[off + i] = mk(cv, sv);
+        }
+        off += cnt;
+        ns *= r2 ? 2 : 4;
+    }
+}
+
 // CNT consecutive FIR outputs starting at window base w (w[i] = tx[j0 - (LT-1) + i]).
 // The taps are wave-uniform and read through a noalias kernel argument, so they arrive by
-// scalar loads in SGPRs and feed v_fmac directly; nothing about them lives in VGPRs.
+// scalar loads as SGPR pairs and feed v_pk_fma_f32 directly: 2 instructions per complex MAC.
 template <int CNT>
-__device__ __forceinline__ void fir_chunk(const float2 *w, const float2 *__restrict__ taps,
-                                          float2 *acc)
+__device__ __forceinline__ void fir_chunk(const v2f *w, const v2f *__restrict__ taps, v2f *acc)
 {
     constexpr int LT = WOFDM_LT;
-    float2 win[CNT + LT - 1];
+    v2f win[CNT + LT - 1];
 #pragma unroll
     for (int i = 0; i < CNT + LT - 1; ++i) win[i] = w[i];
 #pragma unroll
-    for (int r = 0; r < CNT; ++r) acc[r] = make_float2(0.f, 0.f);
+    for (int r = 0; r < CNT; ++r) acc[r] = mk(0.f, 0.f);
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
-        const float2 t = taps[l];
+        const v2f t = taps[l];
+        const v2f tn = mk(-t.y, t.y);
 #pragma unroll
         for (int r = 0; r < CNT; ++r) {
-            const float2 x = win[r + LT - 1 - l];
-            acc[r].x = fmaf(t.x, x.x, acc[r].x);
-            acc[r].x = fmaf(-t.y, x.y, acc[r].x);
-            acc[r].y = fmaf(t.x, x.y, acc[r].y);
-            acc[r].y = fmaf(t.y, x.x, acc[r].y);
+            const v2f x = win[r + LT - 1 - l];
+            acc[r] = __builtin_elementwise_fma(t.xx, x, acc[r]);
+            acc[r] = __builtin_elementwise_fma(tn, x.yx, acc[r]);
         }
     }
 }
 
 template <int RB>
-__device__ __forceinline__ void fir_lane(const float2 *w, const float2 *__restrict__ taps,
-                                         float2 (&acc)[RB])
+__device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ taps, v2f (&acc)[RB])
 {
     constexpr int CH = 6, FULL = RB / CH, REM = RB % CH;
 #pragma unroll
@@ -222,22 +287,39 @@ __device__ __forceinline__ void fir_lane(const float2 *w, const float2 *__restri
 }
 
 // two complex unit normals from one Philox block (philox.h)
-__device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b)
+__device__ __forceinline__ v2f box_muller(uint32_t a, uint32_t b)
 {
     const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
     const float u2 = (float)b * 2.3283064365386963e-10f;
     // -2 ln(u1) = -2 ln2 log2(u1); v_sin/v_cos take revolutions
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-    return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
+    return mk(__builtin_amdgcn_cosf(u2), __builtin_amdgcn_sinf(u2)) * rad;
 }
 
-// One block of stream `stream` of (seed, cell, frame).  The key words are made opaque so the
-// ten round keys are re-derived with scalar adds per call instead of occupying 20 SGPRs.
+// One block of stream `stream` of (seed, cell, frame), Philox4x32-10 as in philox.h with the
+// three-input XORs fused (v_bitop3_b32) and the round keys advanced by scalar adds per call
+// (opaque key: otherwise the 20 round keys sit in SGPRs for the whole frame loop).
 __device__ __forceinline__ philox_out stream_block(uint32_t block, uint32_t f_lo, uint32_t f_hi,
                                                    uint32_t stream_cell, uint32_t k0, uint32_t k1)
 {
     asm volatile("" : "+s"(k0), "+s"(k1));
-    return philox4x32_10(block, f_lo, f_hi, stream_cell, k0, k1);
+    uint32_t c0 = block, c1 = f_lo, c2 = f_hi, c3 = stream_cell;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    philox_out o;
+    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
 }
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -253,10 +335,12 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
     return x;
 }
 
+__device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
+
 template <int N, int K, bool INJECT, bool DUMP>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
-                    const float *__restrict__ g_wrx, const float2 *__restrict__ g_h,
+                    const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin)
 {
     constexpr int LT = WOFDM_LT;
@@ -273,22 +357,19 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
     // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
     using L = wofdm_lds<N>;
-    float2 *tw = reinterpret_cast<float2 *>(smem + L::off_tw);
-    float2 *G = reinterpret_cast<float2 *>(smem + L::off_g);
+    v2f *tw = reinterpret_cast<v2f *>(smem + L::off_tw);
+    v2f *G = reinterpret_cast<v2f *>(smem + L::off_g);
     float *sums = reinterpret_cast<float *>(smem + L::off_sums);
     float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
     float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
-    float2 *tailb = reinterpret_cast<float2 *>(smem + L::off_tail);
-    float2 *fbuf = reinterpret_cast<float2 *>(smem + L::off_fbuf);
+    v2f *tailb = reinterpret_cast<v2f *>(smem + L::off_tail);
+    v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
+    const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
 
-    float2 *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
+    v2f *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
 
-    for (int i = tid; i < p.fbuf_len; i += blockDim.x) fbuf[i] = make_float2(0.f, 0.f);
-    for (int i = tid; i < N; i += blockDim.x) {
-        float sv, cv;
-        sincospif(-2.0f * (float)i / (float)N, &sv, &cv);
-        tw[i] = make_float2(cv, sv);
-    }
+    for (int i = tid; i < p.fbuf_len; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
+    fill_twiddles<N>(tw, tid, (int)blockDim.x);
     __syncthreads();
 
     // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
@@ -367,7 +448,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         ++nfr;
 
         // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
-        float2 v[BPL][4];
+        v2f v[BPL][4];
         uint32_t lab[BPL];
         // the symbol's Philox words are staged in the wave's own (still unused) frame slice
         uint32_t *bw = reinterpret_cast<uint32_t *>(fb);
@@ -399,10 +480,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
                     const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
                     const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-                    v[q][r] = make_float2((float)(2 * li - m1) * qscale, (float)(m1 - 2 * lq) * qscale);
+                    v[q][r] = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
                     if (DUMP) {
                         if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)L;
-                        if (p.dump.X) p.dump.X[s * N + n] = v[q][r];
+                        if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[q][r].x, v[q][r].y);
                     }
                 }
             }
@@ -420,10 +501,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = j + r * NQ;
-                    const float2 x = v[q][r];
+                    const v2f x = v[q][r];
                     auto put = [&](int i) {
-                        const float w = wtx[i];
-                        const float2 val = make_float2(w * x.x, w * x.y);
+                        const v2f val = x * wtx[i];
                         if (i < B || s == S - 1) fb[i] = val;
                         else tailb[s * L::TAIL_MAX + (i - B)] = val;
                     };
@@ -436,12 +516,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         __syncthreads();                                                     // ---- barrier 1
 
         // ------------------------------------------------------------ B: overlap-add, FIR, noise
-        if (s > 0 && lane < beta) fb[lane] = cadd(fb[lane], tailb[(s - 1) * L::TAIL_MAX + lane]);
+        if (s > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s - 1) * L::TAIL_MAX + lane];
         wave_sync();
         if (DUMP) {
             __syncthreads();
             if (p.dump.tx)
-                for (int i = tid; i < p.T; i += blockDim.x) p.dump.tx[i] = fbuf[(LT - 1) + i];
+                for (int i = tid; i < p.T; i += blockDim.x) p.dump.tx[i] = make_float2(fbuf[(LT - 1) + i].x, fbuf[(LT - 1) + i].y);
             __syncthreads();
         }
 
@@ -465,17 +545,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // scalar out of the SGPR file (v_readlane traffic).
         int ch_now = __builtin_amdgcn_readfirstlane(ch);
         asm volatile("" : "+s"(ch_now));
-        const float2 *__restrict__ taps = g_h + ch_now * LT;
-        float2 acc[RB], nz[RB];
+        const v2f *__restrict__ taps = g_h + ch_now * LT;
+        v2f acc[RB], nz[RB];
         fir_lane<RB>(fbuf + j0, taps, acc);        // fbuf + (LT-1) + j0 - (LT-1)
 
         if (INJECT) {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
-                nz[r] = (r < cnt) ? p.unit_noise[inj * NL + j0 + r] : make_float2(0.f, 0.f);
+                nz[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NL + j0 + r) : mk(0.f, 0.f);
         } else {
             constexpr int NBK = RB / 2 + 1;
-            float2 cand[2 * NBK];
+            v2f cand[2 * NBK];
             if (cnt > 0) {
                 const uint32_t b0 = (uint32_t)j0 >> 1;
 #pragma unroll
@@ -487,41 +567,42 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < 2 * NBK; ++b) cand[b] = make_float2(0.f, 0.f);
+                for (int b = 0; b < 2 * NBK; ++b) cand[b] = mk(0.f, 0.f);
             }
             const bool odd = (j0 & 1) != 0;
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const float2 a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
-                const float2 c = odd ? b : a;
-                nz[r] = (r < cnt) ? c : make_float2(0.f, 0.f);
+                const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
+                const v2f c = odd ? b : a;
+                nz[r] = (r < cnt) ? c : mk(0.f, 0.f);
             }
         }
 
-        float ps = 0.f, pn = 0.f;
+        v2f ps2 = mk(0.f, 0.f), pn2 = mk(0.f, 0.f);      // (sum re^2, sum im^2)
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             if (r < cnt) {
-                ps = fmaf(acc[r].x, acc[r].x, ps); ps = fmaf(acc[r].y, acc[r].y, ps);
-                pn = fmaf(nz[r].x, nz[r].x, pn); pn = fmaf(nz[r].y, nz[r].y, pn);
+                ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
+                pn2 = __builtin_elementwise_fma(nz[r], nz[r], pn2);
                 if (DUMP) {
-                    if (p.dump.conv) p.dump.conv[j0 + r] = acc[r];
-                    if (p.dump.unit_noise) p.dump.unit_noise[j0 + r] = nz[r];
+                    if (p.dump.conv) p.dump.conv[j0 + r] = make_float2(acc[r].x, acc[r].y);
+                    if (p.dump.unit_noise) p.dump.unit_noise[j0 + r] = make_float2(nz[r].x, nz[r].y);
                 }
             }
         }
+        float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
         if (!tail_in_idle && tail_total > 0 && s == S - 1) {
             // rare geometry (no idle lanes): trailing samples only feed the power sums
             for (int t = lane; t < tail_total; t += 64) {
                 const int j = S * B + t;
-                float2 c = make_float2(0.f, 0.f);
+                v2f c = mk(0.f, 0.f);
                 for (int l = 0; l < LT; ++l) {
-                    const float2 hh = taps[l];
-                    c = cadd(c, cmul(hh, fbuf[(LT - 1) + j - l]));
+                    const v2f hh = taps[l];
+                    c = c + cmul(hh, fbuf[(LT - 1) + j - l]);
                 }
-                float2 nn;
+                v2f nn;
                 if (INJECT) {
-                    nn = p.unit_noise[inj * NL + j];
+                    nn = ldg2(p.unit_noise + inj * NL + j);
                 } else {
                     const philox_out o = stream_block((uint32_t)j >> 1, f_lo, f_hi,
                                                       (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
@@ -530,8 +611,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 ps += c.x * c.x + c.y * c.y;
                 pn += nn.x * nn.x + nn.y * nn.y;
                 if (DUMP) {
-                    if (p.dump.conv) p.dump.conv[j] = c;
-                    if (p.dump.unit_noise) p.dump.unit_noise[j] = nn;
+                    if (p.dump.conv) p.dump.conv[j] = make_float2(c.x, c.y);
+                    if (p.dump.unit_noise) p.dump.unit_noise[j] = make_float2(nn.x, nn.y);
                 }
             }
         }
@@ -547,9 +628,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 if (r < cnt) {
-                    const float2 y = make_float2(fmaf(g, nz[r].x, acc[r].x), fmaf(g, nz[r].y, acc[r].y));
+                    const v2f y = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
                     fb[lane * RB + r] = y;
-                    if (DUMP && p.dump.rx) p.dump.rx[s * B + lane * RB + r] = y;
+                    if (DUMP && p.dump.rx) p.dump.rx[s * B + lane * RB + r] = make_float2(y.x, y.y);
                 }
             }
         }
@@ -567,13 +648,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int r = 0; r < 4; ++r) {
                     const int t = j + r * NQ;
                     const int m0 = (t + kap + h2) & (N - 1);
-                    const float2 y = fb[gam + m0];
-                    const float w = wrx[m0];
-                    float2 z = make_float2(w * y.x, w * y.y);
+                    v2f z = fb[gam + m0] * wrx[m0];
                     if (m0 < delta) {
-                        const float2 y2 = fb[gam + m0 + N];
                         const float w2 = wrx[m0 + N];
-                        z.x = fmaf(w2, y2.x, z.x); z.y = fmaf(w2, y2.y, z.y);
+                        z = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], z);
                     }
                     v[q][r] = z;
                 }
@@ -588,7 +666,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int j = lane + 64 * q;
                 if (NQ >= 64 * BPL || j < NQ)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p.dump.Y[s * N + j + r * NQ] = v[q][r];
+                    for (int r = 0; r < 4; ++r) p.dump.Y[s * N + j + r * NQ] = make_float2(v[q][r].x, v[q][r].y);
             }
         }
         if (s == 0) {
@@ -603,12 +681,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
                         const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
                         const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-                        const float2 x0 = make_float2((float)(2 * li - m1) * qscale,
-                                                      (float)(m1 - 2 * lq) * qscale);
-                        const float2 y0 = v[q][r];
+                        const v2f x0 = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
+                        const v2f y0 = v[q][r];
                         const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
-                        G[j + r * NQ] = make_float2((x0.x * y0.x + x0.y * y0.y) * inv,
-                                                    (x0.y * y0.x - x0.x * y0.y) * inv);
+                        G[j + r * NQ] = cmul_conj(x0, y0) * inv;          // X0 conj(Y0) / |Y0|^2
                     }
                 }
             }
@@ -624,7 +700,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = j + r * NQ;
-                        const float2 xh = cmul(v[q][r], G[n]);
+                        const v2f xh = cmul(v[q][r], G[n]);
                         int ii = (int)floorf((xh.x * qinv + (float)m1) * 0.5f + 0.5f);
                         int qi = (int)floorf(((float)m1 - xh.y * qinv) * 0.5f + 0.5f);
                         ii = min(max(ii, 0), m1);
@@ -635,7 +711,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         bit_err += __popc(diff);
                         sym_err += diff != 0u;
                         if (DUMP) {
-                            if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = xh;
+                            if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
                             if (p.dump.labels_rx) p.dump.labels_rx[(s - 1) * N + n] = (uint8_t)Lrx;
                         }
                     }
