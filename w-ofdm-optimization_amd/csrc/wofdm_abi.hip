@@ -85,7 +85,7 @@ struct wofdm_plan {
     float2 *d_h = nullptr;
     wofdm_kparams base{};
     wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};
-    int occ = 1, cus = 1;
+    int occ = 1, cus = 1, spw = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -102,7 +102,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     if (force_grid > 0) grid = (uint64_t)force_grid;
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                            dim3(64u * (unsigned)pl->g.S), args, kp.lds_bytes, stream));
+                            dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
     return WOFDM_OK;
 }
 
@@ -196,6 +196,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     kp.lds_bytes = wofdm_lds_bytes(g.N, g.T);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
+    pl->spw = wofdm_spw(g.N, g.S, g.B);
     hipDeviceProp_t prop;
     PLAN_TRY(hipGetDeviceProperties(&prop, device));
     pl->cus = prop.multiProcessorCount;
@@ -205,7 +206,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
                     kp.lds_bytes);
     }
     for (int m = 0; m < 4; ++m) {
-        pl->fn[m] = wofdm_select_kernel(g.N, g.k, m);
+        pl->fn[m] = wofdm_select_kernel(g.N, g.k, pl->spw, m);
         if (!pl->fn[m]) continue;
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[m]),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -213,7 +214,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     }
     int occ = 0;
     PLAN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S, kp.lds_bytes));
+        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S / pl->spw, kp.lds_bytes));
     if (occ < 1) {
         wofdm_plan_destroy(pl);
         return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", kp.lds_bytes);
@@ -241,7 +242,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
-    info[0] = pl->g.S;
+    info[0] = pl->g.S / pl->spw;
     info[1] = (int32_t)pl->base.lds_bytes;
     info[2] = pl->cus * pl->occ;
     info[3] = pl->occ;

@@ -52,11 +52,17 @@ struct wofdm_kparams {
 };
 
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
-static inline int wofdm_rb(int n_fft) { return n_fft / 64 + 1; }   // outputs per lane in the FIR
+// FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
+static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 64 + 1 : 2 * (n_fft / 64) + 2; }
+// symbols per wave: two where the register budget allows it (N <= 256) and S is even
+static inline int wofdm_spw(int n_fft, int S, int B)
+{
+    return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
+}
 
 static inline int wofdm_fbuf_len(int N, int T)
 {
-    return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N) + 8 + 1) / 2 * 2;
+    return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, 2) + 8 + 1) / 2 * 2;
 }
 static inline unsigned wofdm_lds_bytes(int N, int T)
 {
@@ -70,5 +76,5 @@ static inline unsigned wofdm_lds_bytes(int N, int T)
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
                                 const float *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int mode);
+wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode);
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);

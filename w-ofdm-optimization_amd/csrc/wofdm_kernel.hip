@@ -277,15 +277,6 @@ __device__ __forceinline__ void fir_chunk(const v2f *w, const v2f *__restrict__ 
     }
 }
 
-template <int RB>
-__device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ taps, v2f (&acc)[RB])
-{
-    constexpr int CH = 6, FULL = RB / CH, REM = RB % CH;
-#pragma unroll
-    for (int c = 0; c < FULL; ++c) fir_chunk<CH>(w + c * CH, taps, &acc[c * CH]);
-    if constexpr (REM != 0) fir_chunk<REM>(w + FULL * CH, taps, &acc[FULL * CH]);
-}
-
 // two complex unit normals from one Philox block (philox.h)
 __device__ __forceinline__ v2f box_muller(uint32_t a, uint32_t b)
 {
@@ -337,22 +328,46 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 
 __device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
 
-template <int N, int K, bool INJECT, bool DUMP>
-__global__ void __launch_bounds__(1024, WOFDM_MIN_WAVES_PER_SIMD)
+// FIR outputs per lane: one wave covers SPW symbols = SPW*B consecutive samples.  For SPW = 2
+// the count is even and every lane starts on an even sample, so its unit noise is exactly
+// RB/2 Philox blocks (2.5 per symbol instead of 3).
+template <int N, int SPW> struct fir_geo {
+    static constexpr int RB = SPW == 1 ? N / 64 + 1 : 2 * (N / 64) + 2;
+    static constexpr bool EVEN = (SPW % 2 == 0) && (RB % 2 == 0);
+    static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
+    static constexpr int CH = RB <= 6 ? RB : (RB % 5 == 0 ? 5 : 6);
+};
+
+template <int RB, int CH>
+__device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ taps, v2f (&acc)[RB])
+{
+    constexpr int FULL = RB / CH, REM = RB % CH;
+#pragma unroll
+    for (int c = 0; c < FULL; ++c) fir_chunk<CH>(w + c * CH, taps, &acc[c * CH]);
+    if constexpr (REM != 0) fir_chunk<REM>(w + FULL * CH, taps, &acc[FULL * CH]);
+}
+
+template <int N, int K, int SPW, bool INJECT, bool DUMP>
+__global__ void __launch_bounds__(1024 / SPW, WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin)
 {
     constexpr int LT = WOFDM_LT;
-    constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ, RB = geo<N>::RB;
+    constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
+    constexpr bool FULL = geo<N>::FULL;
+    constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
+    constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane0 = tid & 63;
-    // the symbol index is wave-uniform: keep it (and everything derived from it) in SGPRs
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = wv * SPW;                       // first of this wave's SPW symbols
     int lane = lane0;
     const int S = p.S, B = p.B, beta = p.beta, mu = p.mu, rho = p.rho, delta = p.delta;
     const int gam = p.gamma, kap = p.kappa, NL = p.NL;
+    const int W = S / SPW;                         // waves per workgroup
 
     // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
     // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
@@ -366,7 +381,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
 
-    v2f *fb = fbuf + (LT - 1) + s * B;        // this wave's symbol slice of the frame
+    v2f *fbw = fbuf + (LT - 1) + s0 * B;       // this wave's SPW symbol slices of the frame
 
     for (int i = tid; i < p.fbuf_len; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     fill_twiddles<N>(tw, tid, (int)blockDim.x);
@@ -380,6 +395,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr float qscale = 1.0f / qinv;
     constexpr int ks = K == 6 ? 8 : K;
     constexpr int bps = N * ks / 128;             // Philox blocks of data bits per symbol
+    static_assert(SPW * bps <= 64, "data-bit blocks of a wave must fit one pass");
 
     // Work items (cell, frame) are walked with scalar adds/compares only: a 64-bit divide would
     // push the (wave-uniform) loop state into VGPRs and turn every per-cell constant into a
@@ -411,7 +427,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
     auto flush = [&](uint32_t c) {
         const unsigned be = wave_sum_u(bit_err), se = wave_sum_u(sym_err);
-        if (lane == 0 && s > 0) {
+        if (lane == 0) {
             atomicAdd(&p.counts[4 * (size_t)c + 0], (unsigned long long)be);
             atomicAdd(&p.counts[4 * (size_t)c + 2], (unsigned long long)se);
         }
@@ -448,113 +464,127 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         ++nfr;
 
         // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
-        v2f v[BPL][4];
-        uint32_t lab[BPL];
-        // the symbol's Philox words are staged in the wave's own (still unused) frame slice
-        uint32_t *bw = reinterpret_cast<uint32_t *>(fb);
+        v2f v[SPW][BPL][4];
+        uint32_t lab[SPW][BPL];
         if (!INJECT) {
-            if (lane < bps) {
-                const philox_out o = stream_block((uint32_t)(s * bps + lane), f_lo, f_hi,
+            // Philox words of the wave's symbols, staged in the (still unused) frame slices
+            if (lane < SPW * bps) {
+                const int ub = lane / bps, blk = lane % bps;
+                const philox_out o = stream_block((uint32_t)((s0 + ub) * bps + blk), f_lo, f_hi,
                                                   (WOFDM_STREAM_BITS << 28) | cell, seed_lo, seed_hi);
+                uint32_t *bw = reinterpret_cast<uint32_t *>(fbw + ub * B);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bw[4 * lane + i] = o.w[i];
+                for (int i = 0; i < 4; ++i) bw[4 * blk + i] = o.w[i];
             }
             wave_sync();
         }
 #pragma unroll
-        for (int q = 0; q < BPL; ++q) {
-            const int j = lane + 64 * q;
-            lab[q] = 0;
-            if (NQ >= 64 * BPL || j < NQ) {
+        for (int u = 0; u < SPW; ++u) {
+            const int s = s0 + u;
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(fbw + u * B);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = j + r * NQ;
-                    uint32_t L;
-                    if (INJECT) {
-                        L = p.labels[(inj * S + s) * N + n] & lmask;
-                    } else {
-                        const uint32_t bit = (uint32_t)n * (uint32_t)ks;
-                        L = (bw[bit >> 5] >> (bit & 31u)) & lmask;
-                    }
-                    lab[q] |= L << (8 * r);
-                    const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
-                    const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
-                    const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-                    v[q][r] = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
-                    if (DUMP) {
-                        if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)L;
-                        if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[q][r].x, v[q][r].y);
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                lab[u][q] = 0;
+                if (FULL || j < NQ) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = j + r * NQ;
+                        uint32_t Lb;
+                        if (INJECT) {
+                            Lb = p.labels[(inj * S + s) * N + n] & lmask;
+                        } else {
+                            const uint32_t bit = (uint32_t)n * (uint32_t)ks;
+                            Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
+                        }
+                        lab[u][q] |= Lb << (8 * r);
+                        const uint32_t gi = Lb >> half, gq = Lb & (uint32_t)m1;
+                        const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
+                        const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
+                        v[u][q][r] = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
+                        if (DUMP) {
+                            if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
+                            if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[u][q][r].x, v[u][q][r].y);
+                        }
                     }
                 }
             }
         }
-
-        fft_wave<N, +1>(v, fb, tw, lane);          // v = N * x[t], t = j + r N/4
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) fft_wave<N, +1>(v[u], fbw + u * B, tw, lane);   // v = N x[t]
 
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
         // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
         // overlaps the next symbol (m:253-256): parked in tailb until barrier 1.
 #pragma unroll
-        for (int q = 0; q < BPL; ++q) {
-            const int j = lane + 64 * q;
-            if (NQ >= 64 * BPL || j < NQ) {
+        for (int u = 0; u < SPW; ++u) {
+            const int s = s0 + u;
+            v2f *fb = fbw + u * B;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = j + r * NQ;
-                    const v2f x = v[q][r];
-                    auto put = [&](int i) {
-                        const v2f val = x * wtx[i];
-                        if (i < B || s == S - 1) fb[i] = val;
-                        else tailb[s * L::TAIL_MAX + (i - B)] = val;
-                    };
-                    put(t + mu);
-                    if (t >= N - mu) put(t + mu - N);
-                    if (t < rho) put(t + mu + N);
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                if (FULL || j < NQ) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = j + r * NQ;
+                        const v2f x = v[u][q][r];
+                        auto put = [&](int i) {
+                            const v2f val = x * wtx[i];
+                            if (i < B || s == S - 1) fb[i] = val;
+                            else tailb[s * L::TAIL_MAX + (i - B)] = val;
+                        };
+                        put(t + mu);
+                        if (t >= N - mu) put(t + mu - N);
+                        if (t < rho) put(t + mu + N);
+                    }
                 }
             }
         }
         __syncthreads();                                                     // ---- barrier 1
 
-        // ------------------------------------------------------------ B: overlap-add, FIR, noise
-        if (s > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s - 1) * L::TAIL_MAX + lane];
+        // ------------------------------------------------------------ B: overlap-add, noise, FIR
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            const int s = s0 + u;
+            v2f *fb = fbw + u * B;
+            if (s > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s - 1) * L::TAIL_MAX + lane];
+        }
         wave_sync();
         if (DUMP) {
             __syncthreads();
             if (p.dump.tx)
-                for (int i = tid; i < p.T; i += blockDim.x) p.dump.tx[i] = make_float2(fbuf[(LT - 1) + i].x, fbuf[(LT - 1) + i].y);
+                for (int i = tid; i < p.T; i += blockDim.x)
+                    p.dump.tx[i] = make_float2(fbuf[(LT - 1) + i].x, fbuf[(LT - 1) + i].y);
             __syncthreads();
         }
 
-        const int nmain = (B + RB - 1) / RB;
+        // lane -> RB consecutive outputs of the wave's SPW*B samples; the beta+L-1 trailing
+        // samples of the frame (power sums only) ride in the idle lanes of the last waves
+        const int LW = SPW * B;
+        const int nmain = (LW + RB - 1) / RB;
         const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
         const int idle = 64 - nmain;
         const int ntc = (tail_total + RB - 1) / RB;
-        const bool tail_in_idle = idle * S >= ntc;
+        const bool tail_in_idle = idle * W >= ntc;
         int j0 = 0, cnt = 0;
         const bool is_main = lane < nmain;
         if (is_main) {
-            j0 = s * B + lane * RB;
-            cnt = min(RB, B - lane * RB);
+            j0 = s0 * B + lane * RB;
+            cnt = min(RB, LW - lane * RB);
         } else if (tail_in_idle) {
-            const int c = (S - 1 - s) * idle + (lane - nmain);
+            const int c = (W - 1 - wv) * idle + (lane - nmain);
             if (c < ntc) { j0 = S * B + c * RB; cnt = min(RB, tail_total - c * RB); }
         }
 
-        // The tap pointer is made opaque HERE so that the 42 scalar tap loads are issued after
-        // barrier 1 and die with the FIR; hoisted to the loop top they squeeze every other
-        // scalar out of the SGPR file (v_readlane traffic).
-        int ch_now = __builtin_amdgcn_readfirstlane(ch);
-        asm volatile("" : "+s"(ch_now));
-        const v2f *__restrict__ taps = g_h + ch_now * LT;
+        // unit noise of the same samples first (its Philox keys and the FIR's 42 tap scalars
+        // would otherwise fight over the SGPR file)
         v2f acc[RB], nz[RB];
-        fir_lane<RB>(fbuf + j0, taps, acc);        // fbuf + (LT-1) + j0 - (LT-1)
-
         if (INJECT) {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
                 nz[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NL + j0 + r) : mk(0.f, 0.f);
         } else {
-            constexpr int NBK = RB / 2 + 1;
             v2f cand[2 * NBK];
             if (cnt > 0) {
                 const uint32_t b0 = (uint32_t)j0 >> 1;
@@ -569,14 +599,26 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                 for (int b = 0; b < 2 * NBK; ++b) cand[b] = mk(0.f, 0.f);
             }
-            const bool odd = (j0 & 1) != 0;
+            if constexpr (EVEN) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
-                const v2f c = odd ? b : a;
-                nz[r] = (r < cnt) ? c : mk(0.f, 0.f);
+                for (int r = 0; r < RB; ++r) nz[r] = (r < cnt) ? cand[r] : mk(0.f, 0.f);
+            } else {
+                const bool odd = (j0 & 1) != 0;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
+                    const v2f c = odd ? b : a;
+                    nz[r] = (r < cnt) ? c : mk(0.f, 0.f);
+                }
             }
         }
+
+        // The tap pointer is made opaque HERE so that the 42 scalar tap loads are issued after
+        // barrier 1 and die with the FIR.
+        int ch_now = __builtin_amdgcn_readfirstlane(ch);
+        asm volatile("" : "+s"(ch_now));
+        const v2f *__restrict__ taps = g_h + ch_now * LT;
+        fir_lane<RB, fir_geo<N, SPW>::CH>(fbuf + j0, taps, acc);   // fbuf + (LT-1) + j0 - (LT-1)
 
         v2f ps2 = mk(0.f, 0.f), pn2 = mk(0.f, 0.f);      // (sum re^2, sum im^2)
 #pragma unroll
@@ -591,7 +633,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
-        if (!tail_in_idle && tail_total > 0 && s == S - 1) {
+        if (!tail_in_idle && tail_total > 0 && wv == W - 1) {
             // rare geometry (no idle lanes): trailing samples only feed the power sums
             for (int t = lane; t < tail_total; t += 64) {
                 const int j = S * B + t;
@@ -617,20 +659,20 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         ps = wave_sum(ps); pn = wave_sum(pn);
-        if (lane == 0) { sums[s] = ps; sums[S + s] = pn; }
+        if (lane == 0) { sums[wv] = ps; sums[16 + wv] = pn; }
         __syncthreads();                                                     // ---- barrier 2
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
         float Ps = 0.f, Pn = 0.f;
-        for (int w = 0; w < S; ++w) { Ps += sums[w]; Pn += sums[S + w]; }
+        for (int w2 = 0; w2 < W; ++w2) { Ps += sums[w2]; Pn += sums[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         if (is_main) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 if (r < cnt) {
                     const v2f y = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
-                    fb[lane * RB + r] = y;
-                    if (DUMP && p.dump.rx) p.dump.rx[s * B + lane * RB + r] = make_float2(y.x, y.y);
+                    fbw[lane * RB + r] = y;
+                    if (DUMP && p.dump.rx) p.dump.rx[s0 * B + lane * RB + r] = make_float2(y.x, y.y);
                 }
             }
         }
@@ -641,48 +683,56 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
         const int h2 = delta >> 1;
 #pragma unroll
-        for (int q = 0; q < BPL; ++q) {
-            const int j = lane + 64 * q;
-            if (NQ >= 64 * BPL || j < NQ) {
+        for (int u = 0; u < SPW; ++u) {
+            const v2f *fb = fbw + u * B;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = j + r * NQ;
-                    const int m0 = (t + kap + h2) & (N - 1);
-                    v2f z = fb[gam + m0] * wrx[m0];
-                    if (m0 < delta) {
-                        const float w2 = wrx[m0 + N];
-                        z = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], z);
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+                if (FULL || j < NQ) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = j + r * NQ;
+                        const int m0 = (t + kap + h2) & (N - 1);
+                        v2f z = fb[gam + m0] * wrx[m0];
+                        if (m0 < delta) {
+                            const float w2 = wrx[m0 + N];
+                            z = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], z);
+                        }
+                        v[u][q][r] = z;
                     }
-                    v[q][r] = z;
                 }
             }
         }
         wave_sync();
-        fft_wave<N, -1>(v, fb, tw, lane);          // v = Y[n], n = j + r N/4
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) fft_wave<N, -1>(v[u], fbw + u * B, tw, lane);   // v = Y[n]
 
         if (DUMP && p.dump.Y) {
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
-                if (NQ >= 64 * BPL || j < NQ)
+            for (int u = 0; u < SPW; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p.dump.Y[s * N + j + r * NQ] = make_float2(v[q][r].x, v[q][r].y);
-            }
+                for (int q = 0; q < BPL; ++q) {
+                    const int j = lane + 64 * q;
+                    if (FULL || j < NQ)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            p.dump.Y[(s0 + u) * N + j + r * NQ] = make_float2(v[u][q][r].x, v[u][q][r].y);
+                }
         }
-        if (s == 0) {
+        if (wv == 0) {
             // estimatedChannel = Y0 ./ X0 (m:266); we publish its reciprocal X0 ./ Y0
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
-                if (NQ >= 64 * BPL || j < NQ) {
+                if (FULL || j < NQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const uint32_t L = (lab[q] >> (8 * r)) & 0xFFu;
-                        const uint32_t gi = L >> half, gq = L & (uint32_t)m1;
+                        const uint32_t Lb = (lab[0][q] >> (8 * r)) & 0xFFu;
+                        const uint32_t gi = Lb >> half, gq = Lb & (uint32_t)m1;
                         const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
                         const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
                         const v2f x0 = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
-                        const v2f y0 = v[q][r];
+                        const v2f y0 = v[0][q][r];
                         const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
                         G[j + r * NQ] = cmul_conj(x0, y0) * inv;          // X0 conj(Y0) / |Y0|^2
                     }
@@ -692,27 +742,31 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         __syncthreads();                                                     // ---- barrier 3
 
         // ------------------------------------------------------------ D: equalise, demap, count
-        if (s > 0) {
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
-                if (NQ >= 64 * BPL || j < NQ) {
+        for (int u = 0; u < SPW; ++u) {
+            const int s = s0 + u;
+            if (s > 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = j + r * NQ;
-                        const v2f xh = cmul(v[q][r], G[n]);
-                        int ii = (int)floorf((xh.x * qinv + (float)m1) * 0.5f + 0.5f);
-                        int qi = (int)floorf(((float)m1 - xh.y * qinv) * 0.5f + 0.5f);
-                        ii = min(max(ii, 0), m1);
-                        qi = min(max(qi, 0), m1);
-                        const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
-                        const uint32_t Ltx = (lab[q] >> (8 * r)) & 0xFFu;
-                        const uint32_t diff = Ltx ^ Lrx;
-                        bit_err += __popc(diff);
-                        sym_err += diff != 0u;
-                        if (DUMP) {
-                            if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
-                            if (p.dump.labels_rx) p.dump.labels_rx[(s - 1) * N + n] = (uint8_t)Lrx;
+                for (int q = 0; q < BPL; ++q) {
+                    const int j = lane + 64 * q;
+                    if (FULL || j < NQ) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = j + r * NQ;
+                            const v2f xh = cmul(v[u][q][r], G[n]);
+                            int ii = (int)floorf((xh.x * qinv + (float)m1) * 0.5f + 0.5f);
+                            int qi = (int)floorf(((float)m1 - xh.y * qinv) * 0.5f + 0.5f);
+                            ii = min(max(ii, 0), m1);
+                            qi = min(max(qi, 0), m1);
+                            const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
+                            const uint32_t Ltx = (lab[u][q] >> (8 * r)) & 0xFFu;
+                            const uint32_t diff = Ltx ^ Lrx;
+                            bit_err += __popc(diff);
+                            sym_err += diff != 0u;
+                            if (DUMP) {
+                                if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
+                                if (p.dump.labels_rx) p.dump.labels_rx[(s - 1) * N + n] = (uint8_t)Lrx;
+                            }
                         }
                     }
                 }
@@ -733,26 +787,35 @@ __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
     }
 }
 
-template <int N, int K> wofdm_kernel_fn pick_mode(int mode)
+template <int N, int K, int SPW> wofdm_kernel_fn pick_mode(int mode)
 {
     switch (mode) {
-    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, K, false, false>;
-    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, K, true, false>;
-    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, K, false, true>;
-    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, K, true, true>;
+    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, K, SPW, false, false>;
+    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, K, SPW, true, false>;
+    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, K, SPW, false, true>;
+    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, K, SPW, true, true>;
     }
     return nullptr;
 }
 
-template <int N> wofdm_kernel_fn pick(int k, int mode)
+template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode)
+{
+    if (spw == 1) return pick_mode<N, K, 1>(mode);
+    if constexpr (N <= 256) {
+        if (spw == 2) return pick_mode<N, K, 2>(mode);
+    }
+    return nullptr;
+}
+
+template <int N> wofdm_kernel_fn pick(int k, int spw, int mode)
 {
     switch (k) {
 #ifdef WOFDM_ONLY_K
-    case WOFDM_ONLY_K: return pick_mode<N, WOFDM_ONLY_K>(mode);
+    case WOFDM_ONLY_K: return pick_spw<N, WOFDM_ONLY_K>(spw, mode);
 #else
-    case 2: return pick_mode<N, 2>(mode);
-    case 4: return pick_mode<N, 4>(mode);
-    case 6: return pick_mode<N, 6>(mode);
+    case 2: return pick_spw<N, 2>(spw, mode);
+    case 4: return pick_spw<N, 4>(spw, mode);
+    case 6: return pick_spw<N, 6>(spw, mode);
 #endif
     }
     return nullptr;
@@ -760,17 +823,17 @@ template <int N> wofdm_kernel_fn pick(int k, int mode)
 
 }  // namespace
 
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int mode)
+wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode)
 {
     switch (n_fft) {
 #ifdef WOFDM_ONLY_N        // developer builds: one DFT length, faster compile / readable ISA
-    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(bits_per_sc, mode);
+    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(bits_per_sc, spw, mode);
 #else
-    case 64: return pick<64>(bits_per_sc, mode);
-    case 128: return pick<128>(bits_per_sc, mode);
-    case 256: return pick<256>(bits_per_sc, mode);
-    case 512: return pick<512>(bits_per_sc, mode);
-    case 1024: return pick<1024>(bits_per_sc, mode);
+    case 64: return pick<64>(bits_per_sc, spw, mode);
+    case 128: return pick<128>(bits_per_sc, spw, mode);
+    case 256: return pick<256>(bits_per_sc, spw, mode);
+    case 512: return pick<512>(bits_per_sc, spw, mode);
+    case 1024: return pick<1024>(bits_per_sc, spw, mode);
 #endif
     }
     return nullptr;
