@@ -97,6 +97,22 @@ def test_one_frame_stage_by_stage(channels, system, n_fft, cp, k, matlab, inject
     assert abs(int(gc[2]) - int(oc[2])) <= int(mism.sum())
 
 
+@pytest.mark.parametrize("S", [2, 5, 7, 12])
+def test_odd_and_short_frames(channels, S):
+    """symbolsPerTx other than 16: odd S runs the one-symbol-per-wave kernel for every N."""
+    st = W.make_structure("WOLA", 256, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[30:31].astype(np.complex64)
+    cfg = W.make_cfg(st, 4, S, 21, 1, 2, 1, seed=S, frames_per_cell=40, frame_offset=3)
+    snrs = np.array([6.0, 26.0], dtype=np.float32)
+    got = W.run_counts(cfg, w_tx, w_rx, h, snrs)
+    want = O.run(_osys(st, 4, S, 21, True), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                 h.astype(np.complex128), snrs.astype(np.float64), S, 3, 40)
+    assert np.array_equal(got[..., 1], want[..., 1]) and got[0, 0, 0, 1] == 40 * (S - 1) * 256 * 4
+    assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= 2).all()
+    assert (np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)) <= 2).all()
+
+
 @pytest.mark.parametrize("system,n_fft,cp,k,matlab", [("wtx", 64, 16, 2, 1), ("WOLA", 256, 32, 4, 1),
                                                       ("CPW", 256, 14, 6, 0), ("wrx", 512, 32, 4, 1)])
 def test_generate_sweep_counts_match_oracle(channels, system, n_fft, cp, k, matlab):

@@ -83,6 +83,7 @@ struct wofdm_plan {
     uint32_t n_cells = 0;
     float *d_wtx = nullptr, *d_wrx = nullptr, *d_nlin = nullptr;
     float2 *d_h = nullptr;
+    int *d_geo = nullptr;
     wofdm_kparams base{};
     wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};
     int occ = 1, cus = 1, spw = 1;
@@ -100,7 +101,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
     if (grid > total_items) grid = total_items;
     if (force_grid > 0) grid = (uint64_t)force_grid;
-    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin};
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
     return WOFDM_OK;
@@ -187,12 +188,17 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     PLAN_TRY(hipEventCreate(&pl->ev0));
     PLAN_TRY(hipEventCreate(&pl->ev1));
 
+    int geo[WOFDM_G_COUNT];
+    geo[WOFDM_G_S] = g.S; geo[WOFDM_G_MU] = g.mu; geo[WOFDM_G_RHO] = g.rho; geo[WOFDM_G_BETA] = g.beta;
+    geo[WOFDM_G_DELTA] = g.delta; geo[WOFDM_G_GAMMA] = g.gamma; geo[WOFDM_G_KAPPA] = g.kappa;
+    geo[WOFDM_G_L] = g.L; geo[WOFDM_G_P] = g.P; geo[WOFDM_G_B] = g.B; geo[WOFDM_G_T] = g.T;
+    geo[WOFDM_G_NL] = g.NL; geo[WOFDM_G_NSNR] = cfg->n_snr; geo[WOFDM_G_NCH] = cfg->n_channels;
+    geo[WOFDM_G_FBUF] = wofdm_fbuf_len(g.N, g.T);
+    PLAN_TRY(hipMalloc(&pl->d_geo, sizeof geo));
+    PLAN_TRY(hipMemcpy(pl->d_geo, geo, sizeof geo, hipMemcpyHostToDevice));
+
     wofdm_kparams &kp = pl->base;
-    kp.S = g.S; kp.k = g.k; kp.mu = g.mu; kp.rho = g.rho; kp.beta = g.beta; kp.delta = g.delta;
-    kp.gamma = g.gamma; kp.kappa = g.kappa; kp.L = g.L; kp.P = g.P; kp.B = g.B; kp.T = g.T;
-    kp.NL = g.NL; kp.n_snr = cfg->n_snr; kp.n_ch = cfg->n_channels;
     kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
-    kp.fbuf_len = wofdm_fbuf_len(g.N, g.T);
     kp.lds_bytes = wofdm_lds_bytes(g.N, g.T);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
@@ -233,6 +239,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_wrx) (void)hipFree(pl->d_wrx);
     if (pl->d_h) (void)hipFree(pl->d_h);
     if (pl->d_nlin) (void)hipFree(pl->d_nlin);
+    if (pl->d_geo) (void)hipFree(pl->d_geo);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;

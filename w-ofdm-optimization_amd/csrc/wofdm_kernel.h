@@ -32,16 +32,15 @@ template <int N> struct wofdm_lds {
     static constexpr int off_fbuf = off_tail + 8 * 16 * TAIL_MAX;
 };
 
+// geometry array read by the kernel through a laundered pointer (see GEO_PHASE)
+enum { WOFDM_G_S, WOFDM_G_MU, WOFDM_G_RHO, WOFDM_G_BETA, WOFDM_G_DELTA, WOFDM_G_GAMMA, WOFDM_G_KAPPA,
+       WOFDM_G_L, WOFDM_G_P, WOFDM_G_B, WOFDM_G_T, WOFDM_G_NL, WOFDM_G_NSNR, WOFDM_G_NCH, WOFDM_G_FBUF,
+       WOFDM_G_COUNT };
+
 struct wofdm_kparams {
-    // structure: S k mu rho beta delta gamma kappa L, P = N+mu+rho, B = P-beta,
-    // T = beta+S*B
-    int S, k, mu, rho, beta, delta, gamma, kappa, L, P, B, T;
-    int NL;                 // unit-noise samples per frame (T+L-1 or S*B)
-    int n_snr, n_ch;        // cell = (pair*n_snr + snr)*n_ch + ch
     uint32_t n_cells;       // cells covered by this launch, starting at first_cell
     uint32_t first_cell;
     uint32_t inject_base_cell;   // injected arrays are indexed from this cell
-    int fbuf_len;                // float2 entries of the frame buffer
     unsigned lds_bytes;
     uint64_t frames_per_cell, frame_offset;
     uint32_t seed_lo, seed_hi;
@@ -74,7 +73,7 @@ static inline unsigned wofdm_lds_bytes(int N, int T)
 // constants travel as separate noalias arguments so that uniform reads become scalar loads:
 // w_tx[pairs][P], w_rx[pairs][N+delta], h[n_ch][WOFDM_LT] zero padded, noise_lin[n_snr]
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
-                                const float *);
+                                const float *, const int *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
 wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode);
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);

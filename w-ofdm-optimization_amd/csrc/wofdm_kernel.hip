@@ -351,7 +351,7 @@ template <int N, int K, int SPW, bool INJECT, bool DUMP>
 __global__ void __launch_bounds__(1024 / SPW, WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
-                    const float *__restrict__ g_nlin)
+                    const float *__restrict__ g_nlin, const int *__restrict__ gm)
 {
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
@@ -365,9 +365,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s0 = wv * SPW;                       // first of this wave's SPW symbols
     int lane = lane0;
-    const int S = p.S, B = p.B, beta = p.beta, mu = p.mu, rho = p.rho, delta = p.delta;
-    const int gam = p.gamma, kap = p.kappa, NL = p.NL;
-    const int W = S / SPW;                         // waves per workgroup
+    // The structure lengths live in a small device array (gm[WOFDM_G_*]) that every phase
+    // re-reads by scalar loads through a laundered pointer (GEO_PHASE): held in registers for
+    // the whole frame loop they overflow the SGPR file and come back as v_readlane traffic.
+#define GEO_PHASE()                                                                            \
+    const int *gq = gm;                                                                         \
+    asm volatile("" : "+s"(gq))
 
     // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
     // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
@@ -381,9 +384,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
 
-    v2f *fbw = fbuf + (LT - 1) + s0 * B;       // this wave's SPW symbol slices of the frame
-
-    for (int i = tid; i < p.fbuf_len; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
+    for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     fill_twiddles<N>(tw, tid, (int)blockDim.x);
     __syncthreads();
 
@@ -405,16 +406,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     uint32_t cell = p.first_cell;
     uint64_t fidx = blockIdx.x;
     int ch = 0, sn = 0, pair = 0;          // cell = (pair*n_snr + sn)*n_ch + ch
+    const int n_ch = gm[WOFDM_G_NCH], n_snr = gm[WOFDM_G_NSNR];
     {
         uint32_t c = 0;
         while (c < p.first_cell) {
             ++c;
-            if (++ch == p.n_ch) { ch = 0; if (++sn == p.n_snr) { sn = 0; ++pair; } }
+            if (++ch == n_ch) { ch = 0; if (++sn == n_snr) { sn = 0; ++pair; } }
         }
     }
     auto next_cell = [&]() {
         ++cell;
-        if (++ch == p.n_ch) { ch = 0; if (++sn == p.n_snr) { sn = 0; ++pair; } }
+        if (++ch == n_ch) { ch = 0; if (++sn == n_snr) { sn = 0; ++pair; } }
     };
     while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
 
@@ -432,6 +434,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             atomicAdd(&p.counts[4 * (size_t)c + 2], (unsigned long long)se);
         }
         if (tid == 0) {
+            const int S = gm[WOFDM_G_S];
             atomicAdd(&p.counts[4 * (size_t)c + 1], (unsigned long long)nfr * (S - 1) * N * k);
             atomicAdd(&p.counts[4 * (size_t)c + 3], (unsigned long long)nfr * (S - 1) * N);
         }
@@ -445,8 +448,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             if (pair != cur_pair) {
                 __syncthreads();
                 // 1/N of the IDFT (dftmtx(N)'/N, m:370) is folded into the Tx window copy
-                for (int i = tid; i < p.P; i += blockDim.x)
-                    wtx[i] = g_wtx[(size_t)pair * p.P + i] * (1.0f / (float)N);
+                const int P = gm[WOFDM_G_P], delta = gm[WOFDM_G_DELTA];
+                for (int i = tid; i < P; i += blockDim.x)
+                    wtx[i] = g_wtx[(size_t)pair * P + i] * (1.0f / (float)N);
                 for (int i = tid; i < N + delta; i += blockDim.x)
                     wrx[i] = g_wrx[(size_t)pair * (N + delta) + i];
                 __syncthreads();
@@ -463,9 +467,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
         ++nfr;
 
-        // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
         v2f v[SPW][BPL][4];
         uint32_t lab[SPW][BPL];
+        v2f acc[RB], nz[RB];
+        int j0 = 0, cnt = 0;
+        bool is_main;
+        // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
+        {
+        GEO_PHASE();
+        const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], mu = gq[WOFDM_G_MU], rho = gq[WOFDM_G_RHO];
+        v2f *fbw = fbuf + (LT - 1) + s0 * B;       // this wave's SPW symbol slices of the frame
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
             if (lane < SPW * bps) {
@@ -521,6 +532,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         for (int u = 0; u < SPW; ++u) {
             const int s = s0 + u;
             v2f *fb = fbw + u * B;
+            // branch-free target: samples i >= Bs go to the tail buffer, Dt v2f's away from fb+i
+            // (the last symbol has no successor: its fall tail stays in the frame buffer)
+            const int Bs = (s == S - 1) ? 0x3fffffff : B;
+            const int Dt = (int)(tailb + s * L::TAIL_MAX - (fb + B));
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
@@ -529,11 +544,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     for (int r = 0; r < 4; ++r) {
                         const int t = j + r * NQ;
                         const v2f x = v[u][q][r];
-                        auto put = [&](int i) {
-                            const v2f val = x * wtx[i];
-                            if (i < B || s == S - 1) fb[i] = val;
-                            else tailb[s * L::TAIL_MAX + (i - B)] = val;
-                        };
+                        auto put = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = x * wtx[i]; };
                         put(t + mu);
                         if (t >= N - mu) put(t + mu - N);
                         if (t < rho) put(t + mu + N);
@@ -541,9 +552,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         }
+        }
         __syncthreads();                                                     // ---- barrier 1
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
+        {
+        GEO_PHASE();
+        const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
+        const int W = S / SPW;                         // waves per workgroup
+        v2f *fbw = fbuf + (LT - 1) + s0 * B;
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
             const int s = s0 + u;
@@ -554,7 +571,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (DUMP) {
             __syncthreads();
             if (p.dump.tx)
-                for (int i = tid; i < p.T; i += blockDim.x)
+                for (int i = tid; i < gq[WOFDM_G_T]; i += blockDim.x)
                     p.dump.tx[i] = make_float2(fbuf[(LT - 1) + i].x, fbuf[(LT - 1) + i].y);
             __syncthreads();
         }
@@ -567,8 +584,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int idle = 64 - nmain;
         const int ntc = (tail_total + RB - 1) / RB;
         const bool tail_in_idle = idle * W >= ntc;
-        int j0 = 0, cnt = 0;
-        const bool is_main = lane < nmain;
+        is_main = lane < nmain;
         if (is_main) {
             j0 = s0 * B + lane * RB;
             cnt = min(RB, LW - lane * RB);
@@ -579,7 +595,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
         // unit noise of the same samples first (its Philox keys and the FIR's 42 tap scalars
         // would otherwise fight over the SGPR file)
-        v2f acc[RB], nz[RB];
         if (INJECT) {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
@@ -660,9 +675,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         ps = wave_sum(ps); pn = wave_sum(pn);
         if (lane == 0) { sums[wv] = ps; sums[16 + wv] = pn; }
+        }
         __syncthreads();                                                     // ---- barrier 2
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
+        {
+        GEO_PHASE();
+        const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
+        const int gam = gq[WOFDM_G_GAMMA], kap = gq[WOFDM_G_KAPPA];
+        const int W = S / SPW;
+        v2f *fbw = fbuf + (LT - 1) + s0 * B;
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums[w2]; Pn += sums[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
@@ -738,6 +760,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
+        }
         }
         __syncthreads();                                                     // ---- barrier 3
 
