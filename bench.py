@@ -45,14 +45,20 @@ def cpu_baseline(W, st, w_tx, w_rx, h, seed, target_s=15.0):
                       st.circ_shift, h.shape[1], 1)
     args = (osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128),
             SNR_DB, seed)
-    threads = O.threads()
-    O.run(*args, 0, 2 * threads)                         # warm-up (thread pool, page faults)
+    # the threads we may really use: the process's CPU affinity (the GPU box exposes many more
+    # hardware threads than its CPU share), capped by OpenMP's own limit
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(O.threads(), avail, int(os.environ.get("WOFDM_CPU_THREADS", "64"))))
+    O.run(*args, 0, 2 * threads, n_threads=threads)      # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
-    O.run(*args, 0, 8 * threads)
+    O.run(*args, 0, 8 * threads, n_threads=threads)
     rate = 8 * threads / (time.perf_counter() - t0)      # frames per cell per second
     frames = int(max(8 * threads, min(20000, rate * target_s)))
     t0 = time.perf_counter()
-    counts = O.run(*args, 0, frames)
+    counts = O.run(*args, 0, frames, n_threads=threads)
     dt = time.perf_counter() - t0
     syms = frames * 16 * SNR_DB.size
     return dict(value=syms / dt, unit="OFDM symbols/s", cores=threads, kind="port",

@@ -54,7 +54,19 @@ static int sys_check(const wofdm_oracle_sys *s)
  * (dftmtx(N)'/N, main_BER_calculation.m:370; transmitter.py:53-58). */
 void wofdm_oracle_fft(int n, int dir, double *x)
 {
+    /* per-thread twiddle table exp(-2 pi i k / n), k < n/2 (rebuilt when n changes) */
+    static __thread double *tw = NULL;
+    static __thread int tw_n = 0;
     int i, j, len;
+    if (tw_n != n) {
+        free(tw);
+        tw = (double *)malloc(sizeof(double) * (size_t)(n > 1 ? n : 2));
+        for (i = 0; i < n / 2; i++) {
+            tw[2 * i] = cos(-2.0 * M_PI * (double)i / (double)n);
+            tw[2 * i + 1] = sin(-2.0 * M_PI * (double)i / (double)n);
+        }
+        tw_n = n;
+    }
     for (i = 1, j = 0; i < n; i++) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -66,11 +78,10 @@ void wofdm_oracle_fft(int n, int dir, double *x)
         }
     }
     for (len = 2; len <= n; len <<= 1) {
-        double ang = (dir > 0 ? 2.0 : -2.0) * M_PI / (double)len;
-        int half = len >> 1, k;
+        int half = len >> 1, k, step = n / len;
         for (i = 0; i < n; i += len) {
             for (k = 0; k < half; k++) {
-                double wr = cos(ang * k), wi = sin(ang * k);
+                double wr = tw[2 * k * step], wi = dir > 0 ? -tw[2 * k * step + 1] : tw[2 * k * step + 1];
                 double *a = x + 2 * (i + k), *b = x + 2 * (i + k + half);
                 double tr = b[0] * wr - b[1] * wi, ti = b[0] * wi + b[1] * wr;
                 b[0] = a[0] - tr; b[1] = a[1] - ti;
@@ -160,14 +171,20 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
     CL = T + L - 1; NL = wofdm_oracle_noise_len(sys);
     if (!qam_table) { wofdm_oracle_qam_table(k, table_buf); qam_table = table_buf; }
 
-    X  = (double *)malloc(sizeof(double) * 2 * (size_t)S * N);
-    Y  = (double *)malloc(sizeof(double) * 2 * (size_t)S * N);
-    tx = (double *)calloc((size_t)2 * T, sizeof(double));
-    c  = (double *)calloc((size_t)2 * CL, sizeof(double));
-    r  = (double *)malloc(sizeof(double) * 2 * (size_t)S * B);
-    xs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
-    z  = (double *)malloc(sizeof(double) * 2 * (size_t)N);
-    if (!X || !Y || !tx || !c || !r || !xs || !z) { rc = -100; goto done; }
+    {   /* one per-thread workspace, grown on demand (no malloc traffic in the frame loop) */
+        static __thread double *ws = NULL;
+        static __thread size_t ws_len = 0;
+        size_t need = 2 * ((size_t)2 * S * N + T + CL + (size_t)S * B + 2 * (size_t)N);
+        if (ws_len < need) {
+            free(ws);
+            ws = (double *)malloc(sizeof(double) * need);
+            ws_len = ws ? need : 0;
+        }
+        if (!ws) return -100;
+        X = ws; Y = X + 2 * (size_t)S * N; tx = Y + 2 * (size_t)S * N; c = tx + 2 * (size_t)T;
+        r = c + 2 * (size_t)CL; xs = r + 2 * (size_t)S * B; z = xs + 2 * (size_t)N;
+        memset(tx, 0, sizeof(double) * 2 * (size_t)T);
+    }
 
     /* qammod, main_BER_calculation.m:248-249 (Python: np.random.choice of the
      * alphabet, wofdm_simulation.py:179-186) */
@@ -277,7 +294,6 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
     }
     rc = 0;
 done:
-    free(X); free(Y); free(tx); free(c); free(r); free(xs); free(z);
     return rc;
 }
 
