@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
+    # rehearsal of the N>1 code path on a one-GPU box: all ranks on cuda:0, gloo collectives
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -86,10 +88,15 @@ def main():
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
                          % (a.gpus, world))
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     seed = 2
     st = W.make_structure("wtx", 256, 32)
@@ -105,7 +112,16 @@ def main():
     def step(i):
         # rank r simulates frames [(i*world + r)*F, +F) of every cell
         plan.launch((i * world + rank) * F, F, counts, stream)
-        W.distributed.all_reduce_counts(counts)
+        reduce_counts()
+
+    def reduce_counts():
+        if a.rehearse_on_one_gpu and world > 1:      # gloo: reduce through the host
+            torch.cuda.synchronize()
+            t = counts.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            counts.copy_(t)
+        else:
+            W.distributed.all_reduce_counts(counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -127,11 +143,11 @@ def main():
         ev[i][1].record(stream)
         # counters are running sums, so reducing inside the loop would multiply-count; the
         # reduce of the sweep's counters happens once, below, inside the timed region
-    W.distributed.all_reduce_counts(counts)
+    reduce_counts()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in ev]

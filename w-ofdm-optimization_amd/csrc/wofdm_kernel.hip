@@ -22,6 +22,7 @@
 // 64-bit counters go out once per cell.  fp32 VALU + LDS bound; no MFMA.
 #include "wofdm_kernel.h"
 #include "philox.h"
+#include <type_traits>
 
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
@@ -313,11 +314,25 @@ __device__ __forceinline__ philox_out stream_block(uint32_t block, uint32_t f_lo
     return o;
 }
 
+// Sum over the 64 lanes without LDS round trips: four DPP steps give every lane its 16-lane
+// row sum, the four row sums are then read as scalars.  (The reduction sits on the critical path
+// in front of barrier 2; ds_bpermute shuffles cost six dependent LDS latencies there.)
 __device__ __forceinline__ float wave_sum(float x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});    // row_mirror
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 {
@@ -601,29 +616,24 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 nz[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NL + j0 + r) : mk(0.f, 0.f);
         } else {
             v2f cand[2 * NBK];
-            if (cnt > 0) {
-                const uint32_t b0 = (uint32_t)j0 >> 1;
+            // (lanes without outputs compute unused values: every later use is under r < cnt)
+            const uint32_t b0 = (uint32_t)j0 >> 1;
 #pragma unroll
-                for (int b = 0; b < NBK; ++b) {
-                    const philox_out o = stream_block(b0 + b, f_lo, f_hi,
-                                                      (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
-                    cand[2 * b] = box_muller(o.w[0], o.w[1]);
-                    cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < 2 * NBK; ++b) cand[b] = mk(0.f, 0.f);
+            for (int b = 0; b < NBK; ++b) {
+                const philox_out o = stream_block(b0 + b, f_lo, f_hi,
+                                                  (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
+                cand[2 * b] = box_muller(o.w[0], o.w[1]);
+                cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
             }
             if constexpr (EVEN) {
 #pragma unroll
-                for (int r = 0; r < RB; ++r) nz[r] = (r < cnt) ? cand[r] : mk(0.f, 0.f);
+                for (int r = 0; r < RB; ++r) nz[r] = cand[r];
             } else {
                 const bool odd = (j0 & 1) != 0;
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
                     const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
-                    const v2f c = odd ? b : a;
-                    nz[r] = (r < cnt) ? c : mk(0.f, 0.f);
+                    nz[r] = odd ? b : a;
                 }
             }
         }
