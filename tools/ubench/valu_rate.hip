@@ -29,6 +29,18 @@ template <int KIND> __global__ void __launch_bounds__(1024) k(float *out, int it
                 u2 = (uint32_t)(m2 >> 32) ^ (uint32_t)m3; u3 = (uint32_t)(m3 >> 32) ^ (uint32_t)m0;
             } else if (KIND == 3) {   // v_xor_b32
                 u0 ^= u1; u1 ^= u2; u2 ^= u3; u3 ^= u0; u0 ^= u2; u1 ^= u3; u2 ^= u0; u3 ^= u1;
+            } else if (KIND == 5) {   // v_mul_hi_u32
+                u0 = __umulhi(u0, 0xD2511F53u) ^ u1; u1 = __umulhi(u1, 0xCD9E8D57u) ^ u2;
+                u2 = __umulhi(u2, 0xD2511F53u) ^ u3; u3 = __umulhi(u3, 0xCD9E8D57u) ^ u0;
+            } else if (KIND == 6) {   // v_mul_lo_u32
+                u0 = (u0 * 0xD2511F53u) ^ u1; u1 = (u1 * 0xCD9E8D57u) ^ u2;
+                u2 = (u2 * 0xD2511F53u) ^ u3; u3 = (u3 * 0xCD9E8D57u) ^ u0;
+            } else if (KIND == 7) {   // v_pk_add_f32
+                p0 = p0 + pa; p1 = p1 + pb; p2 = p2 + pa; p3 = p3 + pb;
+                p0 = p0 + pb; p1 = p1 + pa; p2 = p2 + pb; p3 = p3 + pa;
+            } else if (KIND == 8) {   // v_cvt_f32_u32 + v_add
+                x0 += (float)u0; x1 += (float)u1; x2 += (float)u2; x3 += (float)u3;
+                u0 += 3; u1 += 5; u2 += 7; u3 += 11;
             } else if (KIND == 4) {   // transcendental v_sin_f32
                 x0 = __builtin_amdgcn_sinf(x0); x1 = __builtin_amdgcn_sinf(x1); x2 = __builtin_amdgcn_sinf(x2); x3 = __builtin_amdgcn_sinf(x3);
                 x4 = __builtin_amdgcn_sinf(x4); x5 = __builtin_amdgcn_sinf(x5); x6 = __builtin_amdgcn_sinf(x6); x7 = __builtin_amdgcn_sinf(x7);
@@ -62,7 +74,7 @@ int main()
     for (int t : {256, 512, 1024}) {
         if (t == 256) { run<0>("v_fma_f32", 256, 8); run<1>("v_pk_fma_f32", 256, 8); run<2>("v_mad_u64_u32", 256, 4); run<3>("v_xor_b32", 256, 8); run<4>("v_sin_f32", 256, 8); }
         if (t == 512) { run<0>("v_fma_f32", 512, 8); run<1>("v_pk_fma_f32", 512, 8); run<2>("v_mad_u64_u32", 512, 4); run<3>("v_xor_b32", 512, 8); run<4>("v_sin_f32", 512, 8); }
-        if (t == 1024) { run<0>("v_fma_f32", 1024, 8); run<1>("v_pk_fma_f32", 1024, 8); run<2>("v_mad_u64_u32", 1024, 4); run<3>("v_xor_b32", 1024, 8); run<4>("v_sin_f32", 1024, 8); }
+        if (t == 1024) { run<5>("mul_hi+xor", 1024, 8); run<6>("mul_lo+xor", 1024, 8); run<7>("v_pk_add_f32", 1024, 8); run<8>("cvt+add+iadd", 1024, 12); run<0>("v_fma_f32", 1024, 8); run<1>("v_pk_fma_f32", 1024, 8); run<2>("v_mad_u64_u32", 1024, 4); run<3>("v_xor_b32", 1024, 8); run<4>("v_sin_f32", 1024, 8); }
     }
     return 0;
 }
