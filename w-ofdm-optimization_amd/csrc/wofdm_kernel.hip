@@ -373,6 +373,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool FULL = geo<N>::FULL;
     constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
     constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
+    // Large DFTs keep RB = N/64+1 noise samples AND FIR outputs per lane alive across barrier 2
+    // (68 VGPRs at N = 1024): the kernel then spills ~115 VGPRs and stalls on scratch.  There (and
+    // only there: at N = 512 the second draw costs more than the spills) the
+    // noise is drawn twice -- once for its power, again (same Philox blocks) for r = c + g n.
+    constexpr bool RENOISE = N >= 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -487,6 +492,36 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         v2f acc[RB], nz[RB];
         int j0 = 0, cnt = 0;
         bool is_main;
+        // unit noise of the lane's RB samples j0.. (randn + 1j*randn, m:290)
+        auto make_noise = [&](v2f (&out)[RB], int NLv) {
+            if (INJECT) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    out[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NLv + j0 + r) : mk(0.f, 0.f);
+            } else {
+                // (lanes without outputs compute unused values: every later use is under r < cnt)
+                v2f cand[2 * NBK];
+                const uint32_t b0 = (uint32_t)j0 >> 1;
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    const philox_out o = stream_block(b0 + b, f_lo, f_hi,
+                                                      (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
+                    cand[2 * b] = box_muller(o.w[0], o.w[1]);
+                    cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
+                }
+                if constexpr (EVEN) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) out[r] = cand[r];
+                } else {
+                    const bool odd = (j0 & 1) != 0;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
+                        out[r] = odd ? b : a;
+                    }
+                }
+            }
+        };
         // ------------------------------------------------------------ A: bits, QAM, IFFT, Tx
         {
         GEO_PHASE();
@@ -610,34 +645,20 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
         // unit noise of the same samples first (its Philox keys and the FIR's 42 tap scalars
         // would otherwise fight over the SGPR file)
-        if (INJECT) {
+        v2f nzB[RB];
+        make_noise(nzB, NL);
+        v2f pn2 = mk(0.f, 0.f);                          // (sum re^2, sum im^2) of the noise
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
-                nz[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NL + j0 + r) : mk(0.f, 0.f);
-        } else {
-            v2f cand[2 * NBK];
-            // (lanes without outputs compute unused values: every later use is under r < cnt)
-            const uint32_t b0 = (uint32_t)j0 >> 1;
-#pragma unroll
-            for (int b = 0; b < NBK; ++b) {
-                const philox_out o = stream_block(b0 + b, f_lo, f_hi,
-                                                  (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
-                cand[2 * b] = box_muller(o.w[0], o.w[1]);
-                cand[2 * b + 1] = box_muller(o.w[2], o.w[3]);
-            }
-            if constexpr (EVEN) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) nz[r] = cand[r];
-            } else {
-                const bool odd = (j0 & 1) != 0;
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    const v2f a = cand[r], b = cand[r + 1 < 2 * NBK ? r + 1 : r];
-                    nz[r] = odd ? b : a;
-                }
+        for (int r = 0; r < RB; ++r) {
+            if (r < cnt) {
+                pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
+                if (DUMP && p.dump.unit_noise) p.dump.unit_noise[j0 + r] = make_float2(nzB[r].x, nzB[r].y);
             }
         }
-
+        if constexpr (!RENOISE) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) nz[r] = nzB[r];
+        }
         // The tap pointer is made opaque HERE so that the 42 scalar tap loads are issued after
         // barrier 1 and die with the FIR.
         int ch_now = __builtin_amdgcn_readfirstlane(ch);
@@ -645,16 +666,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const v2f *__restrict__ taps = g_h + ch_now * LT;
         fir_lane<RB, fir_geo<N, SPW>::CH>(fbuf + j0, taps, acc);   // fbuf + (LT-1) + j0 - (LT-1)
 
-        v2f ps2 = mk(0.f, 0.f), pn2 = mk(0.f, 0.f);      // (sum re^2, sum im^2)
+        v2f ps2 = mk(0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             if (r < cnt) {
                 ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
-                pn2 = __builtin_elementwise_fma(nz[r], nz[r], pn2);
-                if (DUMP) {
-                    if (p.dump.conv) p.dump.conv[j0 + r] = make_float2(acc[r].x, acc[r].y);
-                    if (p.dump.unit_noise) p.dump.unit_noise[j0 + r] = make_float2(nz[r].x, nz[r].y);
-                }
+                if (DUMP && p.dump.conv) p.dump.conv[j0 + r] = make_float2(acc[r].x, acc[r].y);
             }
         }
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
@@ -698,6 +715,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums[w2]; Pn += sums[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
+        if constexpr (RENOISE) make_noise(nz, gq[WOFDM_G_NL]);
         if (is_main) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
