@@ -144,3 +144,41 @@ def test_c5_sweep_sample(channels, n_fft, k):
         want = O.run(_osys(st, k, 16, 21), w_tx.astype(np.float64), w_rx.astype(np.float64),
                      h.astype(np.complex128), snr.astype(np.float64), 5, 0, 6)
         _close(got, want, tol_frac=2e-4)
+
+
+def test_matlab_script_mirror_end_to_end(channels, tmp_path):
+    """main_BER_calculation.m as a function: window .mat files in, ber_results/*.mat out with the
+    reference's variable names; curves vs the oracle through the same cell numbering."""
+    from scipy.io import loadmat, savemat
+    D = W.driver
+    settings = {k: dict(v) for k, v in D.DEFAULT_SETTINGS.items()}
+    settings["generalSettings"].update(ensemble=12, snrValues=np.array([5.0, 20.0, 35.0]))
+    D.save_settings(str(tmp_path / "settingsData.mat"), settings)
+    (tmp_path / "optimized_windows").mkdir()
+    (tmp_path / "channels").mkdir()
+    savemat(str(tmp_path / "channels" / "vehA200channel2.mat"), {"vehA200channel2": channels[:3]})
+    rs = np.random.RandomState(8)
+    st_w = W.make_structure("wtx", 256, 32)
+    xt = np.concatenate(([1.0], np.sort(rs.uniform(.05, .95, 8))[::-1]))
+    savemat(str(tmp_path / "optimized_windows" / "optimal_win_wtx_VehA200_32CP.mat"),
+            {"optimizedWindow": np.diag(W.expand_tx_window(st_w, xt))})
+    st_c = W.make_structure("CPwrx", 256, 14)
+    xr = np.concatenate(([1.0], np.sort(rs.uniform(.05, .45, 5))[::-1]))
+    savemat(str(tmp_path / "optimized_windows" / "optimal_win_CPwrx_VehA200_14CP.mat"),
+            {"optimizedWindow": np.diag(W.expand_rx_window(st_c, xr))})
+    (tmp_path / "optimized_windows" / "run.log").write_text("not a window file")
+    out = D.run_ber_calculation(str(tmp_path / "settingsData.mat"), str(tmp_path / "optimized_windows"),
+                                str(tmp_path / "channels" / "vehA200channel2.mat"),
+                                str(tmp_path / "ber_results"), seed=6, log=None)
+    assert set(out) == {"optimal_win_wtx_VehA200_32CP.mat", "optimal_win_CPwrx_VehA200_14CP.mat"}
+    a = loadmat(str(tmp_path / "ber_results" / "optimized_ber_wtx_32CP.mat"))["berSNR"].ravel()
+    b = loadmat(str(tmp_path / "ber_results" / "rc_ber_wtx_32CP.mat"))["berRCSNR"].ravel()
+    assert a.shape == (3,) and (np.diff(a) < 0).all() and (np.diff(b) < 0).all()
+    # oracle: pair 0 = (optimised Tx, RC Rx), pair 1 = (RC, RC); mean over the 3 channels
+    w_tx = np.stack([W.expand_tx_window(st_w, xt), W.tx_rc_window(st_w)]).astype(np.float32)
+    w_rx = np.stack([W.rx_rc_window(st_w)] * 2).astype(np.float32)
+    want = O.run(_osys(st_w, 4, 16, 21), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                 channels[:3].astype(np.complex64).astype(np.complex128), [5.0, 20.0, 35.0], 6, 0, 12)
+    ber = want[..., 0].sum(axis=2) / want[..., 1].sum(axis=2)
+    assert np.abs(a - ber[0]).max() < 2e-5 and np.abs(b - ber[1]).max() < 2e-5
+    assert (tmp_path / "ber_results" / "optimized_ber_CPwrx_14CP.mat").exists()

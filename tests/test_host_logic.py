@@ -148,3 +148,36 @@ def test_product_never_touches_the_oracle():
     for f in files:
         txt = open(f).read()
         assert "oracle" not in txt.lower(), f
+
+
+def test_channel_generator_matches_reference_fixture(channels):
+    """gen_chan mirror: same numpy seed -> the reference's 100 Veh-A realisations."""
+    np.random.seed(2024)
+    ch = W.channels.gen_channel_file("vehicularA", no_channels=100)
+    assert ch.shape == (21, 100)
+    assert np.abs(ch.T - channels).max() < 1e-13
+    # quirk Q8: deterministic path magnitudes -> every realisation has the same tap-11 peak region
+    assert np.argmax(np.abs(ch), axis=0).min() >= 9
+    rs = np.random.RandomState(1)
+    other = W.channels.gen_chan("vehicularB", 21, 185.3, 5e6, 16 * 256 * 200e-9, 3, rng=rs)
+    assert other.shape == (21, 3)
+
+
+def test_driver_file_formats(tmp_path):
+    from scipy.io import savemat
+    D = W.driver
+    assert D.parse_window_file_name("optimal_win_WOLA_VehA200_16CP.mat") == ("WOLA", 16)
+    assert D.parse_window_file_name("optimal_win_CPwtx_VehA200_32CP.mat") == ("CPwtx", 32)
+    assert D.parse_window_file_name("run.log") is None
+    assert D.parse_window_file_name("optimal_win_foo_VehA200_16CP.mat") is None
+    D.save_settings(str(tmp_path / "settingsData.mat"))
+    s = D.load_settings(str(tmp_path / "settingsData.mat"))
+    assert s["generalSettings"]["numberSubcarriers"] == 256 and s["WOLA"]["tailRx"] == 10
+    assert len(s["generalSettings"]["snrValues"]) == 30
+    st = V.make_structure("wtx", 256, 32)
+    savemat(str(tmp_path / "w.mat"), {"optimizedWindow": np.diag(V.tx_rc_window(st))})
+    w = D.load_window_file(str(tmp_path / "w.mat"))
+    assert np.allclose(w["optimizedWindow"], V.tx_rc_window(st))
+    h = (np.arange(6) + 1j).reshape(2, 3)
+    savemat(str(tmp_path / "c.mat"), {"vehA200channel2": h})
+    assert np.array_equal(D.load_channels_mat(str(tmp_path / "c.mat")), h)

@@ -6,11 +6,15 @@ as ``wofdm_amd`` through the shim module at the repository root.
   variants     structure table, raised-cosine / optimised window vectors  (host, numpy)
   simulation   run_simulation / wOFDMSystem / simulation_fun mirrors + Plan (ctypes -> HIP)
   distributed  frame-range sharding + counter all-reduce
+  driver       main_BER_calculation.m / `-m run_sim` as functions, reference file formats
+  channels     ITU-R tapped-delay-line channel realisations (gen_chan mirror)
   _lib         ctypes binding of libwofdm_hip.so (include/wofdm.h)
 """
 from . import variants  # noqa: F401
 from . import _lib  # noqa: F401
 from . import distributed  # noqa: F401
+from . import channels  # noqa: F401
+from . import driver  # noqa: F401
 from .simulation import (Plan, ber_for_window_file, error_rates, make_cfg,  # noqa: F401
                          results_from_counts, run_counts, run_counts_injected, run_simulation,
                          save_ber_results, simulation_fun, wOFDMSystem)
