@@ -193,16 +193,16 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     geo[WOFDM_G_DELTA] = g.delta; geo[WOFDM_G_GAMMA] = g.gamma; geo[WOFDM_G_KAPPA] = g.kappa;
     geo[WOFDM_G_L] = g.L; geo[WOFDM_G_P] = g.P; geo[WOFDM_G_B] = g.B; geo[WOFDM_G_T] = g.T;
     geo[WOFDM_G_NL] = g.NL; geo[WOFDM_G_NSNR] = cfg->n_snr; geo[WOFDM_G_NCH] = cfg->n_channels;
-    geo[WOFDM_G_FBUF] = wofdm_fbuf_len(g.N, g.T);
+    pl->spw = wofdm_spw(g.N, g.S, g.B);
+    geo[WOFDM_G_FBUF] = wofdm_fbuf_len(g.N, g.T, pl->spw);
     PLAN_TRY(hipMalloc(&pl->d_geo, sizeof geo));
     PLAN_TRY(hipMemcpy(pl->d_geo, geo, sizeof geo, hipMemcpyHostToDevice));
 
     wofdm_kparams &kp = pl->base;
     kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
-    kp.lds_bytes = wofdm_lds_bytes(g.N, g.T);
+    kp.lds_bytes = wofdm_lds_bytes(g.N, g.T, pl->spw);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
-    pl->spw = wofdm_spw(g.N, g.S, g.B);
     hipDeviceProp_t prop;
     PLAN_TRY(hipGetDeviceProperties(&prop, device));
     pl->cus = prop.multiProcessorCount;

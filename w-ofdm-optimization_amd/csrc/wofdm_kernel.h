@@ -20,6 +20,7 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   wtx   float [N + 128]    Tx window / N      (needs cp + cs <= 128)
 //   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)
 //   tail  float2[16][16]     fall tails         (needs tail_tx <= 16)
+//   lut   float2[64]         QAM constellation by label
 //   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
 template <int N> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = 128, TAILRX_MAX = 64;
@@ -29,7 +30,8 @@ template <int N> struct wofdm_lds {
     static constexpr int off_wtx = off_sums + 4 * 32;
     static constexpr int off_wrx = off_wtx + 4 * (N + CPCS_MAX);
     static constexpr int off_tail = off_wrx + 4 * (N + TAILRX_MAX);
-    static constexpr int off_fbuf = off_tail + 8 * 16 * TAIL_MAX;
+    static constexpr int off_lut = off_tail + 8 * 16 * TAIL_MAX;
+    static constexpr int off_fbuf = off_lut + 8 * 64;
 };
 
 // geometry array read by the kernel through a laundered pointer (see GEO_PHASE)
@@ -59,14 +61,14 @@ static inline int wofdm_spw(int n_fft, int S, int B)
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
-static inline int wofdm_fbuf_len(int N, int T)
+static inline int wofdm_fbuf_len(int N, int T, int spw)
 {
-    return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, 2) + 8 + 1) / 2 * 2;
+    return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
-static inline unsigned wofdm_lds_bytes(int N, int T)
+static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
 {
-    const int fixed = 8 * N + 8 * N + 4 * 32 + 4 * (N + 128) + 4 * (N + 64) + 8 * 16 * 16;
-    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T));
+    const int fixed = 8 * N + 8 * N + 4 * 32 + 4 * (N + 128) + 4 * (N + 64) + 8 * 16 * 16 + 8 * 64;
+    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw));
 }
 
 // kernel registry (wofdm_kernel.hip)

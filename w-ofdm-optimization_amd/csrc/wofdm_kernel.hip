@@ -401,11 +401,21 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
     float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
     v2f *tailb = reinterpret_cast<v2f *>(smem + L::off_tail);
+    v2f *qlut = reinterpret_cast<v2f *>(smem + L::off_lut);
     v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
 
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     fill_twiddles<N>(tw, tid, (int)blockDim.x);
+    // constellation table: qammod(label) (Gray, unit average power; m:248-249)
+    if (tid < (1 << K)) {
+        constexpr int hb = K >> 1, mm = (1 << hb) - 1;
+        constexpr float qs = K == 2 ? 0.70710678118654752f : (K == 4 ? 0.31622776601683794f
+                                                                     : 0.15430334996209191f);
+        const uint32_t gi = (uint32_t)tid >> hb, gq = (uint32_t)tid & (uint32_t)mm;
+        const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2)), lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
+        qlut[tid] = mk((float)(2 * li - mm), (float)(mm - 2 * lq)) * qs;
+    }
     __syncthreads();
 
     // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
@@ -413,7 +423,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr uint32_t lmask = (1u << K) - 1u;
     constexpr float qinv = K == 2 ? 1.4142135623730951f : (K == 4 ? 3.1622776601683795f
                                                                    : 6.4807406984078604f);
-    constexpr float qscale = 1.0f / qinv;
     constexpr int ks = K == 6 ? 8 : K;
     constexpr int bps = N * ks / 128;             // Philox blocks of data bits per symbol
     static_assert(SPW * bps <= 64, "data-bit blocks of a wave must fit one pass");
@@ -559,10 +568,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
                         }
                         lab[u][q] |= Lb << (8 * r);
-                        const uint32_t gi = Lb >> half, gq = Lb & (uint32_t)m1;
-                        const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
-                        const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-                        v[u][q][r] = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
+                        v[u][q][r] = qlut[Lb];
                         if (DUMP) {
                             if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
                             if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[u][q][r].x, v[u][q][r].y);
@@ -777,11 +783,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (FULL || j < NQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const uint32_t Lb = (lab[0][q] >> (8 * r)) & 0xFFu;
-                        const uint32_t gi = Lb >> half, gq = Lb & (uint32_t)m1;
-                        const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2));
-                        const int lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-                        const v2f x0 = mk((float)(2 * li - m1), (float)(m1 - 2 * lq)) * qscale;
+                        const v2f x0 = qlut[(lab[0][q] >> (8 * r)) & 0xFFu];
                         const v2f y0 = v[0][q][r];
                         const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
                         G[j + r * NQ] = cmul_conj(x0, y0) * inv;          // X0 conj(Y0) / |Y0|^2
