@@ -181,3 +181,20 @@ def test_driver_file_formats(tmp_path):
     h = (np.arange(6) + 1j).reshape(2, 3)
     savemat(str(tmp_path / "c.mat"), {"vehA200channel2": h})
     assert np.array_equal(D.load_channels_mat(str(tmp_path / "c.mat")), h)
+
+
+def test_interference_closed_form_matches_reference(golden):
+    """interf_power mirror against the reference's own output."""
+    g = golden("interference.npz")
+    for system in SYSTEMS:
+        n_fft, cp, cs, ttx, trx, rm, shift = [int(v) for v in g[system + "_cfg"]]
+        st = V.Structure(system, n_fft, cp, ttx, trx, cs, rm, shift)
+        p = W.interference.interf_power(st, V.tx_rc_window(st), V.rx_rc_window(st), g["h"])
+        want = g[system + "_P_rc"]
+        assert np.abs(p - want).max() < 1e-12 * np.abs(want).max(), system
+        assert abs(W.interference.total_interference(st, V.tx_rc_window(st), V.rx_rc_window(st), g["h"])
+                   - want.sum()) < 1e-12 * want.sum()
+    # a long cyclic prefix and a one-tap channel leave no interference at all
+    st = V.make_structure("CP", 64, 16)
+    p = W.interference.interf_power(st, np.ones(st.sym_len), np.ones(st.rx_win_len), [1.0])
+    assert np.abs(p).max() < 1e-20
