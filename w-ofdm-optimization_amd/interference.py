@@ -9,7 +9,7 @@ Mirrors ``calculate_interference`` (matlab/main_interference_calculation.m:177-2
 built from the same index formulas as the kernels (no dense DFT loops): the Tx map is an IDFT
 matrix with rows picked by the CP/CS copy and scaled by the Tx window, the Rx map is the DFT of
 the windowed fold of SURVEY.md 3.4-10.  It is the deterministic companion of every BER curve
-and the analytic check of the frame pipeline (tests/test_oracle_golden.py).
+and an analytic, RNG-free check of the frame pipeline.
 """
 import numpy as np
 
