@@ -78,6 +78,13 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64/libhsa.  If
+    # this library pulled in /opt/rocm's copy first, a later `import torch` would find "No HIP
+    # GPUs".  Importing torch first (when it is installed) makes both share torch's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s not found: build it with `make -C %s` (hipcc, gfx950). The w-OFDM hot path has "
