@@ -187,7 +187,7 @@ def main():
                                  "dense peak. HBM is not the bound: generate mode moves O(KB) per launch."},
             "ber": ber, "snr_db": SNR_DB.tolist(),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # CPU leg: rank 0 at N=1 only
             base, fsamp, ocounts = cpu_baseline(W, st, w_tx, w_rx, h, seed)
             out["cpu_baseline"] = base
             # BER vs the reference algorithm on the very same frames (same Philox streams)
