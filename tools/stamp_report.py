@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): where a wave's cycles go, from the WOFDM_STAMP diagnostic build.
+
+    WOFDM_LIB=$PWD/ab/lib_stamp.so python tools/stamp_report.py [N] [K]
+
+Reads the per-wave cycle totals the stamped kernel writes behind the counters (phases A-D, the
+three barrier waits, loop control).  Shares, not absolute times: the stamps fence the schedule.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import wofdm_amd as W  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ch = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "channels_vehA.npz"))["h"]
+st = W.make_structure("wtx" if n <= 256 else "WOLA", n, 32)
+snr = np.arange(-5.0, 51.0, 5.0).astype(np.float32)
+cfg = W.make_cfg(st, k, 16, 21, 1, 12, 1, seed=2)
+frames = 62500 * 256 // n
+with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.complex64), snr) as plan:
+    info = plan.info()
+    grid, waves = info["workgroups"], info["waves_per_workgroup"]
+    buf = torch.zeros(4 * 12 + grid * 16 * 8, dtype=torch.int64, device="cuda")
+    ms = plan.launch_timed(0, frames, buf)
+    torch.cuda.synchronize()
+    st_ = buf[48:].cpu().numpy().reshape(grid, 16, 8)[:, :waves, :].astype(np.float64)
+names = ["A bits/QAM/IFFT/tx", "wait barrier 1", "B noise/FIR/power", "wait barrier 2",
+         "C r/Rx/FFT/pilot", "wait barrier 3", "D equalise/demap", "loop control"]
+tot = st_.sum(axis=2)
+print("N=%d k=%d: %.2f ms, %d workgroups x %d waves; mean cycles per wave %.3e" % (n, k, ms, grid, waves, tot.mean()))
+for i, nm in enumerate(names):
+    sh = st_[:, :, i] / tot
+    print("  %-22s all waves %5.1f %%   wave 0 %5.1f %%   last wave %5.1f %%"
+          % (nm, 100 * sh.mean(), 100 * sh[:, 0].mean(), 100 * sh[:, -1].mean()))

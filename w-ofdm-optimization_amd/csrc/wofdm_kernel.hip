@@ -30,6 +30,22 @@
 
 namespace {
 
+#ifdef WOFDM_STAMP
+// Diagnostic build only (tools/stamp_report.py): per-wave cycle totals of the four phases and of
+// the three barrier waits, written behind the counters.  Never defined in the shipped library.
+#define STAMP(slot)                                                                            \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                    \
+        stamp_acc[slot] += now_ - stamp_t;                                                     \
+        stamp_t = now_;                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // Complex samples are 2-wide float vectors: gfx950 issues one wave64 VALU instruction per
 // ~4 cycles per SIMD whether it is v_fma_f32 or v_pk_fma_f32 (tools/ubench/valu_rate.hip:
 // 4.5 vs 5.1 cycles), so the fp32 peak is only reachable with packed math, and complex
@@ -470,7 +486,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         bit_err = 0; sym_err = 0; nfr = 0;
     };
 
+#ifdef WOFDM_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     while (cell < cell_end) {
+        STAMP(7);                                   // loop control, cell changes
         if (cell != cur_cell) {
             if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
             cur_cell = cell;
@@ -609,7 +630,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         }
+        STAMP(0);
         __syncthreads();                                                     // ---- barrier 1
+        STAMP(1);
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
         {
@@ -709,7 +732,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         ps = wave_sum(ps); pn = wave_sum(pn);
         if (lane == 0) { sums[wv] = ps; sums[16 + wv] = pn; }
         }
+        STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
+        STAMP(3);
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
         {
@@ -792,7 +817,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         }
+        STAMP(4);
         __syncthreads();                                                     // ---- barrier 3
+        STAMP(5);
 
         // ------------------------------------------------------------ D: equalise, demap, count
 #pragma unroll
@@ -826,10 +853,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
 
+        STAMP(6);
         fidx += GSTEP;
         while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
     }
     if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
+#ifdef WOFDM_STAMP
+    if (lane0 == 0) {
+        unsigned long long *dst = p.counts + 4 * (size_t)(p.first_cell + p.n_cells)
+                                  + ((size_t)blockIdx.x * 16 + wv) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = stamp_acc[i];
+    }
+#endif
 }
 
 __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
