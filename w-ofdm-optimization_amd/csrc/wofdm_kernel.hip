@@ -130,125 +130,147 @@ template <int N> struct geo {
     }
 };
 
-// Stockham autosort stages on the wave's LDS slice fb[0..N).  Lane data v[q][r] always means
-// element (lane + 64 q) + r N/4, both as the first stage's input and the last stage's output.
-template <int N, int DIR>
-__device__ __forceinline__ void fft_first(v2f (&v)[geo<N>::BPL][4], v2f *fb, int lane)
+// Stockham autosort stages on the wave's LDS slices.  Lane data v[u][q][r] always means element
+// (lane + 64 q) + r N/4 of the wave's u-th symbol, both as the first stage's input and the last
+// stage's output.  Every stage handles the wave's SPW symbols together (slices `sb` apart), so
+// the independent transforms share one write->read turnaround per stage instead of queueing
+// behind each other's fences.
+template <int N, int DIR, int SPW>
+__device__ __forceinline__ void fft_first(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, int lane)
 {
 #pragma unroll
-    for (int q = 0; q < geo<N>::BPL; ++q) {
-        const int j = lane + 64 * q;
-        if (geo<N>::FULL || j < geo<N>::NQ) {
-            radix4<DIR>(v[q]);
+    for (int u = 0; u < SPW; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fb[4 * j + r] = v[q][r];
+        for (int q = 0; q < geo<N>::BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (geo<N>::FULL || j < geo<N>::NQ) {
+                radix4<DIR>(v[u][q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fb[u * sb + 4 * j + r] = v[u][q][r];
+            }
         }
     }
     wave_sync();
 }
 
-template <int N, int NS, int DIR>
-__device__ __forceinline__ void fft_mid4(v2f *fb, const v2f *tw, int lane)
+template <int N, int NS, int DIR, int SPW>
+__device__ __forceinline__ void fft_mid4(v2f *fb, int sb, const v2f *tw, int lane)
 {
-    v2f u[geo<N>::BPL][4];
+    v2f u4[SPW][geo<N>::BPL][4];
     const v2f *t = tw + geo<N>::tw_off(NS);
 #pragma unroll
-    for (int q = 0; q < geo<N>::BPL; ++q) {
-        const int j = lane + 64 * q;
-        if (geo<N>::FULL || j < geo<N>::NQ) {
-            const int k = j & (NS - 1);
+    for (int u = 0; u < SPW; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[q][r] = fb[j + r * geo<N>::NQ];
+        for (int q = 0; q < geo<N>::BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (geo<N>::FULL || j < geo<N>::NQ) {
+                const int k = j & (NS - 1);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) u[q][r] = twid<DIR>(u[q][r], t[3 * k + r - 1]);
-            radix4<DIR>(u[q]);
+                for (int r = 0; r < 4; ++r) u4[u][q][r] = fb[u * sb + j + r * geo<N>::NQ];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) u4[u][q][r] = twid<DIR>(u4[u][q][r], t[3 * k + r - 1]);
+                radix4<DIR>(u4[u][q]);
+            }
         }
     }
     wave_sync();
 #pragma unroll
-    for (int q = 0; q < geo<N>::BPL; ++q) {
-        const int j = lane + 64 * q;
-        if (geo<N>::FULL || j < geo<N>::NQ) {
-            const int k = j & (NS - 1);
+    for (int u = 0; u < SPW; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fb[((j - k) << 2) + k + r * NS] = u[q][r];
+        for (int q = 0; q < geo<N>::BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (geo<N>::FULL || j < geo<N>::NQ) {
+                const int k = j & (NS - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fb[u * sb + ((j - k) << 2) + k + r * NS] = u4[u][q][r];
+            }
         }
     }
     wave_sync();
 }
 
-template <int N, int NS, int DIR>
-__device__ __forceinline__ void fft_mid2(v2f *fb, const v2f *tw, int lane)
+template <int N, int NS, int DIR, int SPW>
+__device__ __forceinline__ void fft_mid2(v2f *fb, int sb, const v2f *tw, int lane)
 {
     constexpr int NB = N / 2, PER = (NB + 63) / 64;
-    v2f y0[PER], y1[PER];
+    v2f y0[SPW][PER], y1[SPW][PER];
     const v2f *t = tw + geo<N>::tw_off(NS);
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int j = lane + 64 * q;
-        if (j < NB) {
-            const int k = j & (NS - 1);
-            const v2f a = fb[j];
-            const v2f b = twid<DIR>(fb[j + NB], t[k]);
-            y0[q] = a + b; y1[q] = a - b;
+    for (int u = 0; u < SPW; ++u) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = lane + 64 * q;
+            if (j < NB) {
+                const int k = j & (NS - 1);
+                const v2f a = fb[u * sb + j];
+                const v2f b = twid<DIR>(fb[u * sb + j + NB], t[k]);
+                y0[u][q] = a + b; y1[u][q] = a - b;
+            }
         }
     }
     wave_sync();
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int j = lane + 64 * q;
-        if (j < NB) {
-            const int k = j & (NS - 1);
-            fb[((j - k) << 1) + k] = y0[q];
-            fb[((j - k) << 1) + k + NS] = y1[q];
+    for (int u = 0; u < SPW; ++u) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = lane + 64 * q;
+            if (j < NB) {
+                const int k = j & (NS - 1);
+                fb[u * sb + ((j - k) << 1) + k] = y0[u][q];
+                fb[u * sb + ((j - k) << 1) + k + NS] = y1[u][q];
+            }
         }
     }
     wave_sync();
 }
 
-template <int N, int DIR>
-__device__ __forceinline__ void fft_last(v2f (&v)[geo<N>::BPL][4], const v2f *fb,
+template <int N, int DIR, int SPW>
+__device__ __forceinline__ void fft_last(v2f (&v)[SPW][geo<N>::BPL][4], const v2f *fb, int sb,
                                          const v2f *tw, int lane)
 {
     const v2f *t = tw + geo<N>::tw_off(geo<N>::NQ);
 #pragma unroll
-    for (int q = 0; q < geo<N>::BPL; ++q) {
-        const int j = lane + 64 * q;
-        if (geo<N>::FULL || j < geo<N>::NQ) {
+    for (int u = 0; u < SPW; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[q][r] = fb[j + r * geo<N>::NQ];
+        for (int q = 0; q < geo<N>::BPL; ++q) {
+            const int j = lane + 64 * q;
+            if (geo<N>::FULL || j < geo<N>::NQ) {
 #pragma unroll
-            for (int r = 1; r < 4; ++r) v[q][r] = twid<DIR>(v[q][r], t[3 * j + r - 1]);
-            radix4<DIR>(v[q]);
+                for (int r = 0; r < 4; ++r) v[u][q][r] = fb[u * sb + j + r * geo<N>::NQ];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v[u][q][r] = twid<DIR>(v[u][q][r], t[3 * j + r - 1]);
+                radix4<DIR>(v[u][q]);
+            }
         }
     }
     wave_sync();
 }
 
-// registers -> (LDS stages) -> registers, natural order in and out
-template <int N, int DIR>
-__device__ __forceinline__ void fft_wave(v2f (&v)[geo<N>::BPL][4], v2f *fb, const v2f *tw, int lane)
+// registers -> (LDS stages) -> registers, natural order in and out, SPW symbols at once
+template <int N, int DIR, int SPW>
+__device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, const v2f *tw,
+                                         int lane)
 {
-    fft_first<N, DIR>(v, fb, lane);
+    fft_first<N, DIR, SPW>(v, fb, sb, lane);
     if constexpr (N == 64) {
-        fft_mid4<N, 4, DIR>(fb, tw, lane);
+        fft_mid4<N, 4, DIR, SPW>(fb, sb, tw, lane);
     } else if constexpr (N == 128) {
-        fft_mid2<N, 4, DIR>(fb, tw, lane);
-        fft_mid4<N, 8, DIR>(fb, tw, lane);
+        fft_mid2<N, 4, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid4<N, 8, DIR, SPW>(fb, sb, tw, lane);
     } else if constexpr (N == 256) {
-        fft_mid4<N, 4, DIR>(fb, tw, lane);
-        fft_mid4<N, 16, DIR>(fb, tw, lane);
+        fft_mid4<N, 4, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid4<N, 16, DIR, SPW>(fb, sb, tw, lane);
     } else if constexpr (N == 512) {
-        fft_mid4<N, 4, DIR>(fb, tw, lane);
-        fft_mid2<N, 16, DIR>(fb, tw, lane);
-        fft_mid4<N, 32, DIR>(fb, tw, lane);
+        fft_mid4<N, 4, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid2<N, 16, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid4<N, 32, DIR, SPW>(fb, sb, tw, lane);
     } else {
         static_assert(N == 1024, "unsupported DFT length");
-        fft_mid4<N, 4, DIR>(fb, tw, lane);
-        fft_mid4<N, 16, DIR>(fb, tw, lane);
-        fft_mid4<N, 64, DIR>(fb, tw, lane);
+        fft_mid4<N, 4, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid4<N, 16, DIR, SPW>(fb, sb, tw, lane);
+        fft_mid4<N, 64, DIR, SPW>(fb, sb, tw, lane);
     }
-    fft_last<N, DIR>(v, fb, tw, lane);
+    fft_last<N, DIR, SPW>(v, fb, sb, tw, lane);
 }
 
 // Fill the per-stage twiddle tables (once per workgroup).
@@ -599,8 +621,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) fft_wave<N, +1>(v[u], fbw + u * B, tw, lane);   // v = N x[t]
+        fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);          // v = N x[t]
 
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
         // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
@@ -785,8 +806,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) fft_wave<N, -1>(v[u], fbw + u * B, tw, lane);   // v = Y[n]
+        fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);          // v = Y[n]
 
         if (DUMP && p.dump.Y) {
 #pragma unroll
