@@ -427,8 +427,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // re-reads by scalar loads through a laundered pointer (GEO_PHASE): held in registers for
     // the whole frame loop they overflow the SGPR file and come back as v_readlane traffic.
 #define GEO_PHASE()                                                                            \
-    const int *gq = gm;                                                                         \
-    asm volatile("" : "+s"(gq))
+    int goff_ = 0;                    /* opaque OFFSET: the pointer keeps its noalias provenance, */ \
+    asm volatile("" : "+s"(goff_));   /* so the reads stay scalar loads (a laundered pointer      */ \
+    const int *__restrict__ gq = gm + goff_   /* turns them into flat vector loads)               */
 
     // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
     // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
@@ -607,8 +608,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         if (INJECT) {
                             Lb = p.labels[(inj * S + s) * N + n] & lmask;
                         } else {
-                            const uint32_t bit = (uint32_t)n * (uint32_t)ks;
-                            Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
+                            // n*ks = j*ks + r*(NQ*ks); the second term is a multiple of 32 bits
+                            const uint32_t bit = (uint32_t)j * (uint32_t)ks;
+                            Lb = (bw[(bit >> 5) + r * (NQ * ks / 32)] >> (bit & 31u)) & lmask;
                         }
                         lab[u][q] |= Lb << (8 * r);
                         v[u][q][r] = qlut[Lb];
