@@ -628,30 +628,40 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
         // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
         // overlaps the next symbol (m:253-256): parked in tailb until barrier 1.
+        // Only suffix copies -- and body copies when rho < beta -- can land in the fall tail
+        // (i >= B): those go to the tail buffer, Dt v2f's away from fb+i, branch-free; the last
+        // symbol has no successor, its tail stays in the frame buffer.  Copies that cannot
+        // exist for this (q, r) under cp, cs <= CPCS_MAX are dropped at compile time.
+        auto tx_write = [&](auto body_may_tail) {
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            const int s = s0 + u;
-            v2f *fb = fbw + u * B;
-            // branch-free target: samples i >= Bs go to the tail buffer, Dt v2f's away from fb+i
-            // (the last symbol has no successor: its fall tail stays in the frame buffer)
-            const int Bs = (s == S - 1) ? 0x3fffffff : B;
-            const int Dt = (int)(tailb + s * L::TAIL_MAX - (fb + B));
+            for (int u = 0; u < SPW; ++u) {
+                const int s = s0 + u;
+                v2f *fb = fbw + u * B;
+                const int Bs = (s == S - 1) ? 0x3fffffff : B;
+                const int Dt = (int)(tailb + s * L::TAIL_MAX - (fb + B));
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
-                if (FULL || j < NQ) {
+                for (int q = 0; q < BPL; ++q) {
+                    const int j = lane + 64 * q;
+                    if (FULL || j < NQ) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int t = j + r * NQ;
-                        const v2f x = v[u][q][r];
-                        auto put = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = x * wtx[i]; };
-                        put(t + mu);
-                        if (t >= N - mu) put(t + mu - N);
-                        if (t < rho) put(t + mu + N);
+                        for (int r = 0; r < 4; ++r) {
+                            const int t = j + r * NQ;
+                            const v2f x = v[u][q][r];
+                            auto put_plain = [&](int i) { fb[i] = x * wtx[i]; };
+                            auto put_tail = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = x * wtx[i]; };
+                            if (decltype(body_may_tail)::value) put_tail(t + mu);
+                            else put_plain(t + mu);
+                            if (63 + 64 * q + r * NQ >= N - L::CPCS_MAX)
+                                if (t >= N - mu) put_plain(t + mu - N);
+                            if (64 * q + r * NQ < L::CPCS_MAX)
+                                if (t < rho) put_tail(t + mu + N);
+                        }
                     }
                 }
             }
-        }
+        };
+        if (rho < gq[WOFDM_G_BETA]) tx_write(std::true_type{});
+        else tx_write(std::false_type{});
         }
         STAMP(0);
         __syncthreads();                                                     // ---- barrier 1
