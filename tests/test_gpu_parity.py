@@ -280,3 +280,31 @@ def test_reference_operator_mirrors(channels, tmp_path):
     assert np.abs(opt - rc).max() < 0.05
     # anchors from the reference run in BASELINE.md section 2 (wtx, N=256, RC windows)
     assert abs(opt[1] - 0.511) < 0.05 and abs(opt[2] - 0.112) < 0.03
+
+
+def test_edge_sizes(channels):
+    """Empty launch, one-tap channel, two-symbol frames, the largest CP+CS the kernel takes."""
+    st = W.make_structure("wtx", 256, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    cfg = W.make_cfg(st, 4, 16, 21, 1, 1, 1, seed=1, frames_per_cell=0)
+    assert (W.run_counts(cfg, w_tx, w_rx, channels[:1].astype(np.complex64), [10.0]) == 0).all()
+    # one tap (n_taps = 1): conv length T, MATLAB noise length T
+    cfg = W.make_cfg(st, 4, 2, 1, 1, 1, 1, seed=3, frames_per_cell=50)
+    got = W.run_counts(cfg, w_tx, w_rx, np.array([[0.8 - 0.3j]], np.complex64), [12.0])
+    want = O.run(_osys(st, 4, 2, 1, True), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                 np.array([[0.8 - 0.3j]], np.complex64).astype(np.complex128), [12.0], 3, 0, 50)
+    assert np.array_equal(got[..., 1], want[..., 1]) and abs(int(got[0, 0, 0, 0]) - int(want[0, 0, 0, 0])) <= 2
+    # cp + cs = 128 (kernel maximum), CPW: cs = tail_tx + tail_rx/2
+    st2 = W.make_structure("CPW", 256, 115)
+    assert st2.cp + st2.cs == 128
+    with pytest.raises(W._lib.WofdmError) as e:       # stride 256+115+13-8 = 376 > 320: FIR tiling limit
+        W.run_counts(W.make_cfg(st2, 4, 16, 21, 1, 1, 1, frames_per_cell=1), W.tx_rc_window(st2),
+                     W.rx_rc_window(st2), channels[:1], [10.0])
+    assert e.value.code == -2
+    st3 = W.make_structure("CPW", 256, 59)             # stride 256+59+13-8 = 320: the limit itself
+    w3t, w3r = W.tx_rc_window(st3).astype(np.float32), W.rx_rc_window(st3).astype(np.float32)
+    cfg = W.make_cfg(st3, 2, 16, 21, 1, 1, 1, seed=5, frames_per_cell=8)
+    got = W.run_counts(cfg, w3t, w3r, channels[:1].astype(np.complex64), [15.0])
+    want = O.run(_osys(st3, 2, 16, 21, True), w3t.astype(np.float64), w3r.astype(np.float64),
+                 channels[:1].astype(np.complex64).astype(np.complex128), [15.0], 5, 0, 8)
+    assert np.array_equal(got[..., 1], want[..., 1]) and abs(int(got[0, 0, 0, 0]) - int(want[0, 0, 0, 0])) <= 2

@@ -190,3 +190,15 @@ def test_run_accumulates_and_shards_exactly(channels):
     assert (whole[..., 1] == 12 * 15 * 64 * 4).all() and (whole[..., 3] == 12 * 15 * 64).all()
     ber = whole[..., 0] / whole[..., 1]
     assert (ber[0, 0] > ber[0, 1]).all()
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """gcc -fsanitize=address,undefined build of the oracle runs every structure family clean."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "selftest"], check=True,
+                   stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")
+    r = subprocess.run([os.path.join(root, "oracle", "selftest_asan")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
