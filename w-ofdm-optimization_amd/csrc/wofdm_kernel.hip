@@ -866,8 +866,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         for (int r = 0; r < 4; ++r) {
                             const int n = j + r * NQ;
                             const v2f xh = cmul(v[u][q][r], G[n]);
-                            int ii = (int)floorf((xh.x * qinv + (float)m1) * 0.5f + 0.5f);
-                            int qi = (int)floorf(((float)m1 - xh.y * qinv) * 0.5f + 0.5f);
+                            // per-axis slicer: level index = floor((+-x*qinv + m1)/2 + 1/2), both axes
+                            // in one packed fma, floor+convert in one instruction each
+                            const v2f lev = __builtin_elementwise_fma(
+                                xh, mk(0.5f * qinv, -0.5f * qinv), mk(0.5f * (float)m1 + 0.5f, 0.5f * (float)m1 + 0.5f));
+                            int ii, qi;
+                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ii) : "v"(lev.x));
+                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(qi) : "v"(lev.y));
                             ii = min(max(ii, 0), m1);
                             qi = min(max(qi, 0), m1);
                             const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
