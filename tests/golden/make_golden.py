@@ -233,12 +233,39 @@ def fixture_interference(ch):
     np.savez(os.path.join(HERE, "interference.npz"), **out)
 
 
+def fixture_window_design(ch):
+    """Window design (optimizers.py:25-873): the reference's Hessians (its own O(P^2 N^2) loops,
+    un-jitted) and the minimisers of its own solvers, at N=32, CP=12, tails 8/10, for the mean
+    of the first 20 channel realisations."""
+    from optimization_tools.optimizers import OptimizerRx, OptimizerTx, OptimizerTxRx
+    n_fft, cp = 32, 12
+    h_avg = ch[:, :20].mean(axis=1)
+    out = {"h_avg": h_avg, "cfg": np.array([n_fft, cp, 8, 10])}
+    for system in ("wtx", "CPwtx", "wrx", "CPwrx", "WOLA", "CPW"):
+        if system in ("wtx", "CPwtx"):
+            m, reg = OptimizerTx(system, n_fft, cp, 8), 1e-12
+        elif system in ("wrx", "CPwrx"):
+            m, reg = OptimizerRx(system, n_fft, cp, 10), 1e-12
+        else:
+            m, reg = OptimizerTxRx(system, n_fft, cp, 8, 10), 1e-16
+        H = m.gen_hessian(m.calculate_chann_matrices(h_avg))
+        Hs = .5 * (H + H.T)                                    # optimizers.py:61-64
+        x, _ = m.optimize(Hs + reg * np.eye(H.shape[0]), 1e-20)
+        out[system + "_H"] = H
+        out[system + "_x"] = np.asarray(x, dtype=np.float64).reshape(-1)
+    np.savez(os.path.join(HERE, "window_design.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["window_design"]:
+        fixture_window_design(np.load(os.path.join(HERE, "channels_vehA.npz"))["h"].T)
+        sys.exit(0)
     ch = fixture_channels()
     fixture_params()
     fixture_stages(ch)
     fixture_ser_replay(ch)
     fixture_interference(ch)
+    fixture_window_design(ch)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
