@@ -256,7 +256,35 @@ def fixture_window_design(ch):
     np.savez(os.path.join(HERE, "window_design.npz"), **out)
 
 
+def fixture_timefreq():
+    """PSD / OBR estimate (timefreq_simulation.py:216-296) with the legacy global generator
+    seeded (the replay draws the same 16-QAM symbols from RandomState(seed)): N=128, CP=12,
+    non-RC tail vectors."""
+    from ofdm_utils import timefreq_simulation as tf
+    rs = np.random.RandomState(77)
+    out = {"cfg": np.array([128, 12])}
+    for i, system in enumerate(("wtx", "CPW", "wrx", "CPwtx")):
+        btx, brx = TAILS[system]
+        n_fft, cp = 128, 12                      # guard band 48 needs N > 96
+        xt, _ = tail_vectors(system, rs)
+        m = tf.wOFDMSystem(system, n_fft, cp, btx, brx, _tmp)
+        win = np.diagflat(reduce_variable_tx(n_fft, cp, m.cs_len, btx) @ xt.reshape(-1, 1))
+        np.random.seed(1000 + i)
+        opt, rc, cpd = m.estimate_obr(win, 200e-9)
+        out[system + "_seed"] = np.array(1000 + i)
+        out[system + "_xt"] = xt
+        for d in (opt, rc, cpd):
+            for k, v in d.items():
+                if k == "f_axis" and i:
+                    continue
+                out[("" if k == "f_axis" else system + "_") + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "timefreq.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["timefreq"]:
+        fixture_timefreq()
+        sys.exit(0)
     if sys.argv[1:] == ["window_design"]:
         fixture_window_design(np.load(os.path.join(HERE, "channels_vehA.npz"))["h"].T)
         sys.exit(0)
@@ -266,6 +294,7 @@ if __name__ == "__main__":
     fixture_ser_replay(ch)
     fixture_interference(ch)
     fixture_window_design(ch)
+    fixture_timefreq()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

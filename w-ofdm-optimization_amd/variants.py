@@ -22,6 +22,8 @@ SYSTEMS = ("wtx", "wrx", "WOLA", "CPW", "CPwtx", "CPwrx", "CP")
 #: python/wofdm_optimization.py:118-123)
 DEFAULT_TAIL_TX = 8
 DEFAULT_TAIL_RX = 10
+TX_WINDOWED = ("wtx", "WOLA", "CPW", "CPwtx")
+RX_WINDOWED = ("wrx", "WOLA", "CPW", "CPwrx")
 
 
 def default_tails(system):
