@@ -84,6 +84,8 @@ struct wofdm_plan {
     float *d_wtx = nullptr, *d_wrx = nullptr, *d_nlin = nullptr;
     float2 *d_h = nullptr;
     int *d_geo = nullptr;
+    float2 *d_nscr = nullptr;          // unit-noise scratch rows, one per workgroup (large DFTs)
+    uint64_t nscr_wgs = 0;
     wofdm_kparams base{};
     wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};
     int occ = 1, cus = 1, spw = 1;
@@ -101,6 +103,15 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
     if (grid > total_items) grid = total_items;
     if (force_grid > 0) grid = (uint64_t)force_grid;
+    const size_t row = wofdm_noise_scratch_len(pl->g.N, pl->spw);
+    if (row && grid > pl->nscr_wgs) {       // only a forced grid can outgrow the plan's scratch
+        HIP_TRY(hipDeviceSynchronize());
+        if (pl->d_nscr) (void)hipFree(pl->d_nscr);
+        pl->d_nscr = nullptr; pl->nscr_wgs = 0;
+        HIP_TRY(hipMalloc(&pl->d_nscr, grid * row * sizeof(float2)));
+        pl->nscr_wgs = grid;
+    }
+    kp.noise_scratch = pl->d_nscr;
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
@@ -226,6 +237,10 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
         return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", kp.lds_bytes);
     }
     pl->occ = occ;
+    if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
+        pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
+        PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
+    }
 #undef PLAN_TRY
     *out = pl;
     return WOFDM_OK;
@@ -240,6 +255,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_h) (void)hipFree(pl->d_h);
     if (pl->d_nlin) (void)hipFree(pl->d_nlin);
     if (pl->d_geo) (void)hipFree(pl->d_geo);
+    if (pl->d_nscr) (void)hipFree(pl->d_nscr);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;

@@ -49,9 +49,15 @@ struct wofdm_kparams {
     unsigned long long *counts;   // [cells][4]
     const uint8_t *labels;  // inject: [cells][frames][S][N]
     const float2  *unit_noise;    // inject: [cells][frames][NL]
+    float2 *noise_scratch;        // generate, N >= WOFDM_NOISE_SCRATCH_MIN_N: [grid][16][RB][64]
     wofdm_kdump dump;
 };
 
+// DFT lengths from which the generated unit noise is parked in HBM scratch between the FIR and
+// the noise-scaling phase instead of registers
+#ifndef WOFDM_NOISE_SCRATCH_MIN_N
+#define WOFDM_NOISE_SCRATCH_MIN_N 1024
+#endif
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
 static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 64 + 1 : 2 * (n_fft / 64) + 2; }
@@ -59,6 +65,12 @@ static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 6
 static inline int wofdm_spw(int n_fft, int S, int B)
 {
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
+}
+
+// float2 elements of noise scratch per workgroup (0: not used for this DFT length)
+static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
+{
+    return n_fft >= WOFDM_NOISE_SCRATCH_MIN_N ? (size_t)16 * 64 * wofdm_rb(n_fft, spw) : 0;
 }
 
 static inline int wofdm_fbuf_len(int N, int T, int spw)

@@ -411,11 +411,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool FULL = geo<N>::FULL;
     constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
     constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
-    // Large DFTs keep RB = N/64+1 noise samples AND FIR outputs per lane alive across barrier 2
-    // (68 VGPRs at N = 1024): the kernel then spills ~115 VGPRs and stalls on scratch.  There (and
-    // only there: at N = 512 the second draw costs more than the spills) the
-    // noise is drawn twice -- once for its power, again (same Philox blocks) for r = c + g n.
-    constexpr bool RENOISE = N >= 1024;
+    // Large DFTs would keep RB = N/64+1 noise samples AND FIR outputs per lane alive across
+    // barrier 2 (68 VGPRs at N = 1024) and spill.  There the unit noise is parked in a per-workgroup
+    // HBM scratch row ([wave][r][lane]: 512-byte coalesced rows, written and read back by the
+    // same lane, L2-resident) instead of registers; with injected noise it is simply re-read.
+    constexpr bool RENOISE = N >= WOFDM_NOISE_SCRATCH_MIN_N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -720,6 +720,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if constexpr (!RENOISE) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) nz[r] = nzB[r];
+        } else if (!INJECT) {
+            v2f *ns = reinterpret_cast<v2f *>(p.noise_scratch)
+                      + ((size_t)blockIdx.x * 16 + wv) * (RB * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) ns[r * 64] = nzB[r];
         }
         // The tap pointer is made opaque HERE so that the 42 scalar tap loads are issued after
         // barrier 1 and die with the FIR.
@@ -779,7 +784,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums[w2]; Pn += sums[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
-        if constexpr (RENOISE) make_noise(nz, gq[WOFDM_G_NL]);
+        if constexpr (RENOISE) {
+            if (INJECT) {
+                make_noise(nz, gq[WOFDM_G_NL]);
+            } else {
+                const v2f *ns = reinterpret_cast<const v2f *>(p.noise_scratch)
+                                + ((size_t)blockIdx.x * 16 + wv) * (RB * 64) + lane;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) nz[r] = ns[r * 64];
+            }
+        }
         if (is_main) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
