@@ -89,5 +89,21 @@ static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
                                 const float *, const int *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode);
+// one translation unit per DFT length (wofdm_kernel.hip with -DWOFDM_TU_N=<N>)
+wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode);
+wofdm_kernel_fn wofdm_select_kernel_n128(int bits_per_sc, int spw, int mode);
+wofdm_kernel_fn wofdm_select_kernel_n256(int bits_per_sc, int spw, int mode);
+wofdm_kernel_fn wofdm_select_kernel_n512(int bits_per_sc, int spw, int mode);
+wofdm_kernel_fn wofdm_select_kernel_n1024(int bits_per_sc, int spw, int mode);
+static inline wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode)
+{
+    switch (n_fft) {
+    case 64: return wofdm_select_kernel_n64(bits_per_sc, spw, mode);
+    case 128: return wofdm_select_kernel_n128(bits_per_sc, spw, mode);
+    case 256: return wofdm_select_kernel_n256(bits_per_sc, spw, mode);
+    case 512: return wofdm_select_kernel_n512(bits_per_sc, spw, mode);
+    case 1024: return wofdm_select_kernel_n1024(bits_per_sc, spw, mode);
+    }
+    return nullptr;
+}
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);

@@ -962,24 +962,23 @@ template <int N> wofdm_kernel_fn pick(int k, int spw, int mode)
 
 }  // namespace
 
-wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode)
-{
-    switch (n_fft) {
-#ifdef WOFDM_ONLY_N        // developer builds: one DFT length, faster compile / readable ISA
-    case WOFDM_ONLY_N: return pick<WOFDM_ONLY_N>(bits_per_sc, spw, mode);
-#else
-    case 64: return pick<64>(bits_per_sc, spw, mode);
-    case 128: return pick<128>(bits_per_sc, spw, mode);
-    case 256: return pick<256>(bits_per_sc, spw, mode);
-    case 512: return pick<512>(bits_per_sc, spw, mode);
-    case 1024: return pick<1024>(bits_per_sc, spw, mode);
+// This file is compiled once per DFT length (-DWOFDM_TU_N=<N>, see the Makefile) so that the
+// kernel family builds in parallel; wofdm_abi.hip dispatches on n_fft.
+#ifndef WOFDM_TU_N
+#error "compile with -DWOFDM_TU_N=<64|128|256|512|1024>"
 #endif
-    }
-    return nullptr;
+#define WOFDM_CAT2(a, b) a##b
+#define WOFDM_CAT(a, b) WOFDM_CAT2(a, b)
+
+wofdm_kernel_fn WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N)(int bits_per_sc, int spw, int mode)
+{
+    return pick<WOFDM_TU_N>(bits_per_sc, spw, mode);
 }
 
+#if WOFDM_TU_N == 64
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s)
 {
     hipLaunchKernelGGL(philox_kat_kernel, dim3(1), dim3(64), 0, s, ctr_key_dev, out_dev);
     return hipGetLastError();
 }
+#endif
