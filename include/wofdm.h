@@ -123,6 +123,16 @@ int wofdm_plan_dump_frame(wofdm_plan *plan, uint32_t cell, uint64_t frame,
                           const uint8_t *labels, const float *unit_noise,
                           uint64_t *counts, wofdm_dump *out);
 
+/* Subcarrier allocation: active[n_fft] (host), non-zero = bin n carries data.  Unloaded bins
+ * transmit zero and are left out of the channel estimate and of all four counters, which then
+ * count (S-1) * n_active subcarriers per frame.  NULL restores "every bin loaded".  Replaces the
+ * zero-padding `symbolsInOFDM = [zeros(S,offset) transmittedSymbols zeros(S,offset)]` + ifftshift of
+ * matlab/main_channel_mask.m:387-390 and the `offset+1:end-offset` selections of 367-369 (there:
+ * bins [0,N/4) and [3N/4,N)); also the guard-band `subcar_alloc_mat` of
+ * python/ofdm_utils/timefreq_simulation.py:223-233.  The data-bit stream keeps one slot per bin.
+ * Synchronises the device; do not call while launches of this plan are in flight elsewhere. */
+int wofdm_plan_set_allocation(wofdm_plan *plan, const uint8_t *active);
+
 /* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
  * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
 int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);

@@ -18,7 +18,8 @@ class OracleSys(C.Structure):
     """Mirror of wofdm_oracle_sys (one w-OFDM structure)."""
     _fields_ = [(n, C.c_int32) for n in (
         "n_fft", "bits_per_sc", "syms_per_frame", "cp", "cs", "tail_tx", "tail_rx",
-        "prefix_rm", "circ_shift", "n_taps", "noise_before_truncate")]
+        "prefix_rm", "circ_shift", "n_taps", "noise_before_truncate")] + [
+        ("active", C.c_void_p), ("tx_mask", C.c_void_p)]
 
     @property
     def P(self):
@@ -86,9 +87,20 @@ def _c(a):
 
 
 def make_sys(n_fft, bits_per_sc, syms_per_frame, cp, cs, tail_tx, tail_rx, prefix_rm,
-             circ_shift, n_taps, noise_before_truncate=1):
-    return OracleSys(n_fft, bits_per_sc, syms_per_frame, cp, cs, tail_tx, tail_rx, prefix_rm,
-                     circ_shift, n_taps, noise_before_truncate)
+             circ_shift, n_taps, noise_before_truncate=1, active=None, tx_mask=None):
+    """active: [N] bool subcarrier allocation; tx_mask: [2P-1] DFT-domain mask gains
+    (main_channel_mask.m variant); the arrays are kept alive on the returned object."""
+    sys = OracleSys(n_fft, bits_per_sc, syms_per_frame, cp, cs, tail_tx, tail_rx, prefix_rm,
+                    circ_shift, n_taps, noise_before_truncate)
+    if active is not None:
+        sys._active = np.ascontiguousarray(np.asarray(active) != 0, dtype=np.uint8)
+        assert sys._active.shape == (n_fft,)
+        sys.active = sys._active.ctypes.data
+    if tx_mask is not None:
+        sys._tx_mask = np.ascontiguousarray(tx_mask, dtype=np.float64)
+        assert sys._tx_mask.shape == (2 * sys.P - 1,)
+        sys.tx_mask = sys._tx_mask.ctypes.data
+    return sys
 
 
 def noise_len(sys):

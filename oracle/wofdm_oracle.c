@@ -194,6 +194,10 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
             if (lab >= (unsigned)M) { rc = -8; goto done; }
             X[2 * ((size_t)s * N + n)]     = qam_table[2 * lab];
             X[2 * ((size_t)s * N + n) + 1] = qam_table[2 * lab + 1];
+            if (sys->active && !sys->active[n]) {      /* main_channel_mask.m:387-390 */
+                X[2 * ((size_t)s * N + n)] = 0.0;
+                X[2 * ((size_t)s * N + n) + 1] = 0.0;
+            }
         }
 
     /* wofdm_tx, main_BER_calculation.m:358-376: IDFT (1/N), add_redundancy
@@ -260,7 +264,9 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
      * biterr 272 (np.mean(!=), 235). */
     for (s = 1; s < S; s++)
         for (n = 0; n < N; n++) {
-            double y0r = Y[2 * n], y0i = Y[2 * n + 1];
+            double y0r, y0i;
+            if (sys->active && !sys->active[n]) continue;   /* main_channel_mask.m:367-369 */
+            y0r = Y[2 * n]; y0i = Y[2 * n + 1];
             double x0r = X[2 * n], x0i = X[2 * n + 1];
             double xd = x0r * x0r + x0i * x0i;
             double hr = (y0r * x0r + y0i * x0i) / xd, hi = (y0i * x0r - y0r * x0i) / xd;
@@ -279,10 +285,14 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
             if (dump && dump->labels_rx) dump->labels_rx[(size_t)(s - 1) * N + n] = (uint8_t)lab_rx;
         }
 
-    counts[0] += bit_err;
-    counts[1] += (uint64_t)(S - 1) * N * k;
-    counts[2] += sym_err;
-    counts[3] += (uint64_t)(S - 1) * N;
+    {
+        int nact = N;
+        if (sys->active) for (nact = 0, n = 0; n < N; n++) nact += sys->active[n] != 0;
+        counts[0] += bit_err;
+        counts[1] += (uint64_t)(S - 1) * nact * k;
+        counts[2] += sym_err;
+        counts[3] += (uint64_t)(S - 1) * nact;
+    }
 
     if (dump) {
         if (dump->X)    memcpy(dump->X, X, sizeof(double) * 2 * (size_t)S * N);

@@ -40,6 +40,12 @@ typedef struct {
     int32_t n_taps;         /* L  : channel taps                                        */
     int32_t noise_before_truncate; /* 1 = MATLAB order (main_BER_calculation.m:260-261),
                                       0 = Python order (wofdm_simulation.py:208-215)    */
+    /* main_channel_mask.m variant (both NULL = main_BER_calculation.m):                */
+    const uint8_t *active;  /* [N] non-zero = bin carries data (m:387-390 zero padding +
+                               ifftshift; Rx selection m:367-369); NULL = all bins      */
+    const double *tx_mask;  /* [2P-1] DFT-domain gains, natural bin order, of the
+                               per-symbol spectral mask dft_rc_filt (m:398-417);
+                               NULL = no mask                                           */
 } wofdm_oracle_sys;
 
 /* Optional per-frame stage dumps (any pointer may be NULL). Complex arrays are

@@ -1,0 +1,124 @@
+"""GPU parity of the main_channel_mask.m variant: subcarrier allocation
+(half-band loading) and the per-symbol spectral Tx mask, through the C ABI, against the oracle
+on the same Philox streams."""
+import numpy as np
+import pytest
+
+import wofdm_amd as W
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+STAGE_RTOL = 2e-5
+
+
+def _osys(st, k, S, n_taps, matlab, active=None, tx_mask=None):
+    return O.make_sys(st.n_fft, k, S, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm,
+                      st.circ_shift, n_taps, 1 if matlab else 0, active=active, tx_mask=tx_mask)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _half_band(n):
+    a = np.zeros(n, bool)
+    a[:n // 4] = True
+    a[3 * n // 4:] = True
+    return a
+
+
+def _check_decisions(gd, od, gc, oc, k, active):
+    mism = (gd["labels_rx"] != od["labels_rx"]) & active[None, :]
+    if mism.any():
+        a = np.sqrt(2 * (2 ** k - 1) / 3)
+        z = od["Xhat"][mism] * a
+        edge = np.minimum(np.abs((z.real / 2) - np.round(z.real / 2)) * 2,
+                          np.abs((z.imag / 2) - np.round(z.imag / 2)) * 2)
+        assert (edge < 1e-3).all()
+    assert abs(int(gc[0]) - int(oc[0])) <= 2 * int(mism.sum())
+    assert abs(int(gc[2]) - int(oc[2])) <= int(mism.sum())
+
+
+ALLOC_CASES = [("wtx", 256, 32, 4, "half"), ("WOLA", 256, 22, 4, "half"), ("CPW", 64, 16, 2, "half"),
+               ("CPwrx", 128, 20, 6, "random"), ("wrx", 512, 32, 4, "guard"), ("WOLA", 1024, 32, 6, "half"),
+               ("CP", 256, 16, 4, "single")]
+
+
+def _allocation(kind, n):
+    if kind == "half":
+        return _half_band(n)
+    if kind == "guard":                       # timefreq_simulation.py:223-233, guard band 48
+        a = np.zeros(n, bool)
+        a[1:n // 2 - 48 + 1] = True
+        a[n // 2 + 48:] = True
+        return a
+    if kind == "single":
+        a = np.zeros(n, bool)
+        a[n // 4 + 3] = True
+        return a
+    return np.random.RandomState(n).rand(n) < 0.6
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k,kind", ALLOC_CASES)
+@pytest.mark.parametrize("inject", [False, True])
+def test_allocation_one_frame_stage_by_stage(channels, system, n_fft, cp, k, kind, inject):
+    S, seed, frame, cell = 16, 5, 4242, 3
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[20:22].astype(np.complex64)
+    snrs = np.array([10.0, 24.0], dtype=np.float32)
+    active = _allocation(kind, n_fft)
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True, active=active)
+    lab, noise = O.gen_labels(osys, seed, cell, frame), O.gen_noise(osys, seed, cell, frame)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64),
+                     h[1].astype(np.complex128), float(snrs[1]), lab, noise, dump=True)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plan.set_allocation(active)
+        gc, gd = plan.dump_frame(cell, frame, *((lab, noise.astype(np.complex64)) if inject else ()))
+    nact = int(active.sum())
+    assert np.array_equal(gd["labels_tx"], lab)
+    assert int(gc[1]) == int(oc[1]) == (S - 1) * nact * k and int(gc[3]) == int(oc[3]) == (S - 1) * nact
+    assert np.all(gd["X"][:, ~active] == 0)
+    assert _rel(gd["X"], od["X"]) < 1e-6
+    for stage in ("tx", "conv", "rx", "Y"):
+        assert _rel(gd[stage], od[stage]) < STAGE_RTOL, stage
+    _check_decisions(gd, od, gc, oc, k, active)
+
+
+@pytest.mark.parametrize("system,n_fft,k", [("wtx", 256, 4), ("CPW", 256, 6), ("WOLA", 1024, 2)])
+def test_allocation_sweep_counts_match_oracle(channels, system, n_fft, k):
+    S, seed, F, off = 16, 31, 20, 77
+    st = W.make_structure(system, n_fft, 24)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[3:5].astype(np.complex64)
+    snrs = np.array([2.0, 15.0, 30.0], dtype=np.float32)
+    active = _half_band(n_fft)
+    cfg = W.make_cfg(st, k, S, 21, 2, 3, 1, seed=seed, frames_per_cell=F, frame_offset=off)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plan.set_allocation(active)
+        got = plan.run(off, F)
+        plan.set_allocation(None)                       # back to every bin loaded
+        full = plan.run(off, F)
+    want = O.run(_osys(st, k, S, 21, True, active=active), w_tx.astype(np.float64),
+                 w_rx.astype(np.float64), h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    assert got[0, 0, 0, 1] == F * (S - 1) * (n_fft // 2) * k
+    bits = float(want[0, 0, 0, 1])
+    assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
+    assert (np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
+    assert full[0, 0, 0, 1] == F * (S - 1) * n_fft * k
+    ref_full = O.run(_osys(st, k, S, 21, True), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                     h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    assert (np.abs(full[..., 0].astype(np.int64) - ref_full[..., 0].astype(np.int64)) <= max(2, 1e-4 * 2 * bits)).all()
+
+
+def test_allocation_rejects_bad_input(channels):
+    st = W.make_structure("wtx", 64, 16)
+    cfg = W.make_cfg(st, 2, 16, 21, 1, 1, 1)
+    with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), channels[:1].astype(np.complex64),
+                np.array([10.0], np.float32)) as plan:
+        with pytest.raises(W._lib.WofdmError):
+            plan.set_allocation(np.zeros(64, bool))
+        with pytest.raises(ValueError):
+            plan.set_allocation(np.ones(32, bool))

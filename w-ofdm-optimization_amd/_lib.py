@@ -25,7 +25,7 @@ EXPORTS = (
     "wofdm_version", "wofdm_device_count", "wofdm_last_error", "wofdm_noise_len",
     "wofdm_plan_create", "wofdm_plan_destroy", "wofdm_plan_launch", "wofdm_plan_launch_timed",
     "wofdm_plan_launch_injected", "wofdm_plan_dump_frame", "wofdm_plan_info", "wofdm_run",
-    "wofdm_run_injected", "wofdm_philox_kat",
+    "wofdm_run_injected", "wofdm_philox_kat", "wofdm_plan_set_allocation",
 )
 
 
@@ -102,6 +102,7 @@ def load():
     L.wofdm_plan_launch_injected.argtypes = [vp, u64, vp, vp, vp, vp]
     L.wofdm_plan_dump_frame.argtypes = [vp, C.c_uint32, u64, vp, vp, vp, C.POINTER(Dump)]
     L.wofdm_plan_info.argtypes = [vp, vp]
+    L.wofdm_plan_set_allocation.argtypes = [vp, vp]
     L.wofdm_run.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp]
     L.wofdm_run_injected.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.wofdm_philox_kat.argtypes = [C.c_int, vp, vp, vp]

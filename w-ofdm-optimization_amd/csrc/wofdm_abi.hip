@@ -87,7 +87,9 @@ struct wofdm_plan {
     float2 *d_nscr = nullptr;          // unit-noise scratch rows, one per workgroup (large DFTs)
     uint64_t nscr_wgs = 0;
     wofdm_kparams base{};
-    wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};
+    wofdm_kernel_fn fn[WOFDM_VAR_COUNT][4] = {};
+    int var = WOFDM_VAR_PLAIN;         // kernel variant in use (wofdm_plan_set_allocation)
+    uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     int occ = 1, cus = 1, spw = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -97,7 +99,7 @@ namespace {
 int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, int force_grid,
            hipStream_t stream)
 {
-    wofdm_kernel_fn fn = pl->fn[mode];
+    wofdm_kernel_fn fn = pl->fn[pl->var][mode];
     if (!fn) return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d", pl->g.N);
     if (total_items == 0) return WOFDM_OK;
     uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
@@ -112,7 +114,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         pl->nscr_wgs = grid;
     }
     kp.noise_scratch = pl->d_nscr;
-    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo};
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
     return WOFDM_OK;
@@ -206,6 +208,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     geo[WOFDM_G_NL] = g.NL; geo[WOFDM_G_NSNR] = cfg->n_snr; geo[WOFDM_G_NCH] = cfg->n_channels;
     pl->spw = wofdm_spw(g.N, g.S, g.B);
     geo[WOFDM_G_FBUF] = wofdm_fbuf_len(g.N, g.T, pl->spw);
+    geo[WOFDM_G_NACT] = g.N;
     PLAN_TRY(hipMalloc(&pl->d_geo, sizeof geo));
     PLAN_TRY(hipMemcpy(pl->d_geo, geo, sizeof geo, hipMemcpyHostToDevice));
 
@@ -222,16 +225,18 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
         return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)",
                     kp.lds_bytes);
     }
-    for (int m = 0; m < 4; ++m) {
-        pl->fn[m] = wofdm_select_kernel(g.N, g.k, pl->spw, m);
-        if (!pl->fn[m]) continue;
-        PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[m]),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kp.lds_bytes));
-    }
+    for (int v = 0; v < WOFDM_VAR_COUNT; ++v)
+        for (int m = 0; m < 4; ++m) {
+            pl->fn[v][m] = wofdm_select_kernel(g.N, g.k, pl->spw, m, v);
+            if (!pl->fn[v][m]) continue;
+            PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[v][m]),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kp.lds_bytes));
+        }
     int occ = 0;
     PLAN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_MODE_GEN]), 64 * g.S / pl->spw, kp.lds_bytes));
+        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_VAR_PLAIN][WOFDM_MODE_GEN]), 64 * g.S / pl->spw,
+        kp.lds_bytes));
     if (occ < 1) {
         wofdm_plan_destroy(pl);
         return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", kp.lds_bytes);
@@ -256,9 +261,33 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_nlin) (void)hipFree(pl->d_nlin);
     if (pl->d_geo) (void)hipFree(pl->d_geo);
     if (pl->d_nscr) (void)hipFree(pl->d_nscr);
+    if (pl->d_amask) (void)hipFree(pl->d_amask);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
+    return WOFDM_OK;
+}
+
+int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
+{
+    if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
+    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(hipDeviceSynchronize());           // no launch of this plan may still read the mask
+    const int N = pl->g.N, NQ = N / 4;
+    int nact = N;
+    if (active) {
+        nact = 0;
+        std::vector<uint32_t> words((size_t)NQ, 0u);
+        for (int n = 0; n < N; ++n) {
+            if (active[n]) ++nact;
+            else words[(size_t)(n % NQ)] |= 0x80u << (8 * (n / NQ));
+        }
+        if (nact == 0) return fail(WOFDM_E_INVALID, "allocation loads no subcarrier");
+        if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->d_amask, words.data(), (size_t)NQ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    pl->var = (active && nact < N) ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN;
+    HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_NACT, &nact, sizeof(int), hipMemcpyHostToDevice));
     return WOFDM_OK;
 }
 

@@ -37,6 +37,7 @@ template <int N> struct wofdm_lds {
 // geometry array read by the kernel through a laundered pointer (see GEO_PHASE)
 enum { WOFDM_G_S, WOFDM_G_MU, WOFDM_G_RHO, WOFDM_G_BETA, WOFDM_G_DELTA, WOFDM_G_GAMMA, WOFDM_G_KAPPA,
        WOFDM_G_L, WOFDM_G_P, WOFDM_G_B, WOFDM_G_T, WOFDM_G_NL, WOFDM_G_NSNR, WOFDM_G_NCH, WOFDM_G_FBUF,
+       WOFDM_G_NACT,      // loaded subcarriers (WOFDM_VAR_ALLOC)
        WOFDM_G_COUNT };
 
 struct wofdm_kparams {
@@ -87,22 +88,24 @@ static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
 // constants travel as separate noalias arguments so that uniform reads become scalar loads:
 // w_tx[pairs][P], w_rx[pairs][N+delta], h[n_ch][WOFDM_LT] zero padded, noise_lin[n_snr]
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
-                                const float *, const int *);
+                                const float *, const int *, const uint32_t *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
+// kernel variants: every subcarrier loaded / a subcarrier allocation mask
+enum { WOFDM_VAR_PLAIN = 0, WOFDM_VAR_ALLOC = 1, WOFDM_VAR_COUNT };
 // one translation unit per DFT length (wofdm_kernel.hip with -DWOFDM_TU_N=<N>)
-wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode);
-wofdm_kernel_fn wofdm_select_kernel_n128(int bits_per_sc, int spw, int mode);
-wofdm_kernel_fn wofdm_select_kernel_n256(int bits_per_sc, int spw, int mode);
-wofdm_kernel_fn wofdm_select_kernel_n512(int bits_per_sc, int spw, int mode);
-wofdm_kernel_fn wofdm_select_kernel_n1024(int bits_per_sc, int spw, int mode);
-static inline wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode)
+wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n128(int bits_per_sc, int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n256(int bits_per_sc, int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n512(int bits_per_sc, int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n1024(int bits_per_sc, int spw, int mode, int var);
+static inline wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode, int var)
 {
     switch (n_fft) {
-    case 64: return wofdm_select_kernel_n64(bits_per_sc, spw, mode);
-    case 128: return wofdm_select_kernel_n128(bits_per_sc, spw, mode);
-    case 256: return wofdm_select_kernel_n256(bits_per_sc, spw, mode);
-    case 512: return wofdm_select_kernel_n512(bits_per_sc, spw, mode);
-    case 1024: return wofdm_select_kernel_n1024(bits_per_sc, spw, mode);
+    case 64: return wofdm_select_kernel_n64(bits_per_sc, spw, mode, var);
+    case 128: return wofdm_select_kernel_n128(bits_per_sc, spw, mode, var);
+    case 256: return wofdm_select_kernel_n256(bits_per_sc, spw, mode, var);
+    case 512: return wofdm_select_kernel_n512(bits_per_sc, spw, mode, var);
+    case 1024: return wofdm_select_kernel_n1024(bits_per_sc, spw, mode, var);
     }
     return nullptr;
 }

@@ -400,12 +400,17 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
     if constexpr (REM != 0) fir_chunk<REM>(w + FULL * CH, taps, &acc[FULL * CH]);
 }
 
-template <int N, int K, int SPW, bool INJECT, bool DUMP>
+// VAR: 0 = every subcarrier loaded (main_BER_calculation.m); 1 = subcarrier allocation: only the
+// bins flagged in g_amask carry data, the others transmit zero and are not counted
+// (main_channel_mask.m:387-390, 367-371)
+template <int N, int K, int SPW, bool INJECT, bool DUMP, int VAR>
 __global__ void __launch_bounds__(1024 / SPW, WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
-                    const float *__restrict__ g_nlin, const int *__restrict__ gm)
+                    const float *__restrict__ g_nlin, const int *__restrict__ gm,
+                    const uint32_t *__restrict__ g_amask)
 {
+    constexpr bool ALLOC = VAR >= 1;
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
     constexpr bool FULL = geo<N>::FULL;
@@ -503,8 +508,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         if (tid == 0) {
             const int S = gm[WOFDM_G_S];
-            atomicAdd(&p.counts[4 * (size_t)c + 1], (unsigned long long)nfr * (S - 1) * N * k);
-            atomicAdd(&p.counts[4 * (size_t)c + 3], (unsigned long long)nfr * (S - 1) * N);
+            const int nact = ALLOC ? gm[WOFDM_G_NACT] : N;      // loaded subcarriers
+            atomicAdd(&p.counts[4 * (size_t)c + 1], (unsigned long long)nfr * (S - 1) * nact * k);
+            atomicAdd(&p.counts[4 * (size_t)c + 3], (unsigned long long)nfr * (S - 1) * nact);
         }
         bit_err = 0; sym_err = 0; nfr = 0;
     };
@@ -601,6 +607,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int j = lane + 64 * q;
                 lab[u][q] = 0;
                 if (FULL || j < NQ) {
+                    // byte r of the word: 0x80 when subcarrier j + r N/4 is NOT loaded; the flag
+                    // rides in the label word (labels use 6 bits at most) down to phase D
+                    uint32_t am = 0;
+                    if constexpr (ALLOC) am = g_amask[j] & 0x80808080u;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = j + r * NQ;
@@ -614,11 +624,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                         lab[u][q] |= Lb << (8 * r);
                         v[u][q][r] = qlut[Lb];
+                        if constexpr (ALLOC) {
+                            if ((am >> (8 * r)) & 0x80u) v[u][q][r] = mk(0.f, 0.f);
+                        }
                         if (DUMP) {
                             if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
                             if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[u][q][r].x, v[u][q][r].y);
                         }
                     }
+                    if constexpr (ALLOC) lab[u][q] |= am;
                 }
             }
         }
@@ -854,7 +868,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (FULL || j < NQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const v2f x0 = qlut[(lab[0][q] >> (8 * r)) & 0xFFu];
+                        v2f x0 = qlut[(lab[0][q] >> (8 * r)) & lmask];
+                        if constexpr (ALLOC) {
+                            if ((lab[0][q] >> (8 * r)) & 0x80u) x0 = mk(0.f, 0.f);   // G = 0 there
+                        }
                         const v2f y0 = v[0][q][r];
                         const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
                         G[j + r * NQ] = cmul_conj(x0, y0) * inv;          // X0 conj(Y0) / |Y0|^2
@@ -891,7 +908,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             qi = min(max(qi, 0), m1);
                             const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
                             const uint32_t Ltx = (lab[u][q] >> (8 * r)) & 0xFFu;
-                            const uint32_t diff = Ltx ^ Lrx;
+                            uint32_t diff = Ltx ^ Lrx;
+                            if constexpr (ALLOC) {
+                                if (Ltx & 0x80u) diff = 0u;              // not loaded: not counted
+                            }
                             bit_err += __popc(diff);
                             sym_err += diff != 0u;
                             if (DUMP) {
@@ -926,35 +946,44 @@ __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
     }
 }
 
-template <int N, int K, int SPW> wofdm_kernel_fn pick_mode(int mode)
+template <int N, int K, int SPW, int VAR> wofdm_kernel_fn pick_mode(int mode)
 {
     switch (mode) {
-    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, K, SPW, false, false>;
-    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, K, SPW, true, false>;
-    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, K, SPW, false, true>;
-    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, K, SPW, true, true>;
+    case WOFDM_MODE_GEN: return wofdm_frames_kernel<N, K, SPW, false, false, VAR>;
+    case WOFDM_MODE_INJECT: return wofdm_frames_kernel<N, K, SPW, true, false, VAR>;
+    case WOFDM_MODE_DUMP_GEN: return wofdm_frames_kernel<N, K, SPW, false, true, VAR>;
+    case WOFDM_MODE_DUMP_INJECT: return wofdm_frames_kernel<N, K, SPW, true, true, VAR>;
     }
     return nullptr;
 }
 
-template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode)
+template <int N, int K, int SPW> wofdm_kernel_fn pick_var(int mode, int var)
 {
-    if (spw == 1) return pick_mode<N, K, 1>(mode);
-    if constexpr (N <= 256) {
-        if (spw == 2) return pick_mode<N, K, 2>(mode);
+    switch (var) {
+    case WOFDM_VAR_PLAIN: return pick_mode<N, K, SPW, WOFDM_VAR_PLAIN>(mode);
+    case WOFDM_VAR_ALLOC: return pick_mode<N, K, SPW, WOFDM_VAR_ALLOC>(mode);
     }
     return nullptr;
 }
 
-template <int N> wofdm_kernel_fn pick(int k, int spw, int mode)
+template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
+{
+    if (spw == 1) return pick_var<N, K, 1>(mode, var);
+    if constexpr (N <= 256) {
+        if (spw == 2) return pick_var<N, K, 2>(mode, var);
+    }
+    return nullptr;
+}
+
+template <int N> wofdm_kernel_fn pick(int k, int spw, int mode, int var)
 {
     switch (k) {
 #ifdef WOFDM_ONLY_K
-    case WOFDM_ONLY_K: return pick_spw<N, WOFDM_ONLY_K>(spw, mode);
+    case WOFDM_ONLY_K: return pick_spw<N, WOFDM_ONLY_K>(spw, mode, var);
 #else
-    case 2: return pick_spw<N, 2>(spw, mode);
-    case 4: return pick_spw<N, 4>(spw, mode);
-    case 6: return pick_spw<N, 6>(spw, mode);
+    case 2: return pick_spw<N, 2>(spw, mode, var);
+    case 4: return pick_spw<N, 4>(spw, mode, var);
+    case 6: return pick_spw<N, 6>(spw, mode, var);
 #endif
     }
     return nullptr;
@@ -970,9 +999,9 @@ template <int N> wofdm_kernel_fn pick(int k, int spw, int mode)
 #define WOFDM_CAT2(a, b) a##b
 #define WOFDM_CAT(a, b) WOFDM_CAT2(a, b)
 
-wofdm_kernel_fn WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N)(int bits_per_sc, int spw, int mode)
+wofdm_kernel_fn WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N)(int bits_per_sc, int spw, int mode, int var)
 {
-    return pick<WOFDM_TU_N>(bits_per_sc, spw, mode);
+    return pick<WOFDM_TU_N>(bits_per_sc, spw, mode, var);
 }
 
 #if WOFDM_TU_N == 64

@@ -57,6 +57,7 @@ class Plan:
             C.byref(self._h_plan), C.byref(cfg), self.device, self._w_tx.ctypes.data,
             self._w_rx.ctypes.data, self._h.ctypes.data, self._snr.ctypes.data))
         self.noise_len = self.lib.wofdm_noise_len(C.byref(cfg))
+        self.n_active = cfg.n_fft
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -87,6 +88,19 @@ class Plan:
         _lib.check(self.lib.wofdm_plan_info(self._h_plan, a))
         return dict(waves_per_workgroup=a[0], lds_bytes=a[1], workgroups=a[2],
                     workgroups_per_cu=a[3], compute_units=a[4])
+
+    def set_allocation(self, active):
+        """Subcarrier allocation (``wofdm_plan_set_allocation``): ``active`` [N] truthy = bin
+        carries data; None = every bin (main_channel_mask.m:387-390, 367-369)."""
+        if active is None:
+            _lib.check(self.lib.wofdm_plan_set_allocation(self._h_plan, None))
+            self.n_active = self.cfg.n_fft
+            return
+        a = np.ascontiguousarray(np.asarray(active).reshape(-1) != 0, dtype=np.uint8)
+        if a.shape != (self.cfg.n_fft,):
+            raise ValueError("allocation must have n_fft = %d entries" % self.cfg.n_fft)
+        _lib.check(self.lib.wofdm_plan_set_allocation(self._h_plan, a.ctypes.data))
+        self.n_active = int(a.sum())
 
     def new_counts(self):
         """Zeroed device counter tensor [pairs][n_snr][n_channels][4] (int64 bit pattern of the
