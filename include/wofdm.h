@@ -133,6 +133,16 @@ int wofdm_plan_dump_frame(wofdm_plan *plan, uint32_t cell, uint64_t frame,
  * Synchronises the device; do not call while launches of this plan are in flight elsewhere. */
 int wofdm_plan_set_allocation(wofdm_plan *plan, const uint8_t *active);
 
+/* Per-symbol spectral Tx mask: mask[2P-1] (host), DFT-domain gains in natural bin order, P =
+ * n_fft+cp+cs.  Every windowed symbol is zero-padded to 2P-1 samples, its DFT multiplied by the
+ * mask and transformed back; the first P samples replace the symbol, the remaining P-1 are added
+ * to the first P-1 samples of the NEXT symbol's row before the overlap-add (the last symbol's
+ * spill is dropped).  Replaces `dft_rc_filt` (matlab/main_channel_mask.m:398-417; its mask is
+ * `ifftshift(gen_raised_cosine(floor((2P-1)/2), rollOff, 2P-1))`, 402-405, 443-458).  Needs
+ * n_fft <= 512 (the mask's impulse response is staged in LDS), else WOFDM_E_UNSUPPORTED.  NULL
+ * removes the mask.  Synchronises the device. */
+int wofdm_plan_set_tx_mask(wofdm_plan *plan, const float *mask);
+
 /* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
  * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
 int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);

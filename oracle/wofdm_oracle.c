@@ -204,14 +204,65 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
      * (419-439: CP = last mu samples in front, CS = first rho samples behind),
      * diagonal Tx window; then the overlap-add + serialise of 253-259
      * (wofdm_simulation.py:187-203): symbol s starts at s*B. */
-    for (s = 0; s < S; s++) {
-        memcpy(xs, X + 2 * (size_t)s * N, sizeof(double) * 2 * N);
-        wofdm_oracle_fft(N, +1, xs);
-        for (i = 0; i < P; i++) {
-            int src = ((i - mu) % N + N) % N;
-            tx[2 * (s * B + i)]     += w_tx[i] * xs[2 * src];
-            tx[2 * (s * B + i) + 1] += w_tx[i] * xs[2 * src + 1];
+    if (!sys->tx_mask) {
+        for (s = 0; s < S; s++) {
+            memcpy(xs, X + 2 * (size_t)s * N, sizeof(double) * 2 * N);
+            wofdm_oracle_fft(N, +1, xs);
+            for (i = 0; i < P; i++) {
+                int src = ((i - mu) % N + N) % N;
+                tx[2 * (s * B + i)]     += w_tx[i] * xs[2 * src];
+                tx[2 * (s * B + i) + 1] += w_tx[i] * xs[2 * src + 1];
+            }
         }
+    } else {
+        /* main_channel_mask.m:381-417: the windowed symbols (rows of P samples) go through
+         * dft_rc_filt before the overlap-add: zero-pad to Lm = 2P-1, DFT, multiply by the mask,
+         * inverse DFT; samples [0,P) stay in the row, samples [P,2P-1) are added to the first
+         * P-1 samples of the NEXT row (filterTail, 411-415); the last row's spill is dropped. */
+        const int Lm = 2 * P - 1;
+        double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)Lm);      /* e^{-2 pi i q / Lm} */
+        double *row = (double *)malloc(sizeof(double) * 2 * (size_t)P);
+        double *spec = (double *)malloc(sizeof(double) * 2 * (size_t)Lm);
+        double *rows = (double *)calloc((size_t)(S + 1) * P * 2, sizeof(double));
+        int q, kk;
+        if (!cs || !row || !spec || !rows) { free(cs); free(row); free(spec); free(rows); rc = -100; goto done; }
+        for (q = 0; q < Lm; q++) {
+            cs[2 * q] = cos(2.0 * M_PI * q / Lm); cs[2 * q + 1] = -sin(2.0 * M_PI * q / Lm);
+        }
+        for (s = 0; s < S; s++) {
+            memcpy(xs, X + 2 * (size_t)s * N, sizeof(double) * 2 * N);
+            wofdm_oracle_fft(N, +1, xs);
+            for (i = 0; i < P; i++) {
+                int src = ((i - mu) % N + N) % N;
+                row[2 * i] = w_tx[i] * xs[2 * src]; row[2 * i + 1] = w_tx[i] * xs[2 * src + 1];
+            }
+            for (kk = 0; kk < Lm; kk++) {               /* DFT of the zero-padded row x mask */
+                double ar = 0.0, ai = 0.0;
+                for (i = 0; i < P; i++) {
+                    const double *w = cs + 2 * (int)(((long)kk * i) % Lm);
+                    ar += row[2 * i] * w[0] - row[2 * i + 1] * w[1];
+                    ai += row[2 * i] * w[1] + row[2 * i + 1] * w[0];
+                }
+                spec[2 * kk] = ar * sys->tx_mask[kk]; spec[2 * kk + 1] = ai * sys->tx_mask[kk];
+            }
+            for (i = 0; i < Lm; i++) {                  /* inverse DFT, 1/Lm */
+                double ar = 0.0, ai = 0.0;
+                double *dst;
+                for (kk = 0; kk < Lm; kk++) {
+                    const double *w = cs + 2 * (int)(((long)kk * i) % Lm);
+                    ar += spec[2 * kk] * w[0] + spec[2 * kk + 1] * w[1];    /* conj twiddle */
+                    ai += spec[2 * kk + 1] * w[0] - spec[2 * kk] * w[1];
+                }
+                dst = (i < P) ? rows + 2 * ((size_t)s * P + i) : rows + 2 * ((size_t)(s + 1) * P + (i - P));
+                dst[0] += ar / Lm; dst[1] += ai / Lm;
+            }
+        }
+        for (s = 0; s < S; s++)                          /* overlap-add + serialise, m:426-432 */
+            for (i = 0; i < P; i++) {
+                tx[2 * (s * B + i)]     += rows[2 * ((size_t)s * P + i)];
+                tx[2 * (s * B + i) + 1] += rows[2 * ((size_t)s * P + i) + 1];
+            }
+        free(cs); free(row); free(spec); free(rows);
     }
 
     /* conv(channel, transmittedSignal), main_BER_calculation.m:260

@@ -122,3 +122,97 @@ def test_allocation_rejects_bad_input(channels):
             plan.set_allocation(np.zeros(64, bool))
         with pytest.raises(ValueError):
             plan.set_allocation(np.ones(32, bool))
+
+
+# ---------------------------------------------------------------------------- spectral Tx mask
+from wofdm_amd import channel_mask as CM  # noqa: E402
+
+MASK_CASES = [("wtx", 256, 32, 4), ("WOLA", 256, 22, 4), ("CPW", 64, 16, 2), ("CPwrx", 128, 20, 6),
+              ("wrx", 512, 32, 4), ("CP", 256, 16, 4), ("CPwtx", 256, 10, 6)]
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k", MASK_CASES)
+@pytest.mark.parametrize("inject", [False, True])
+def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject):
+    S, seed, frame, cell = 16, 9, 777, 1
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[40:42].astype(np.complex64)
+    snrs = np.array([26.0], dtype=np.float32)
+    active = CM.half_band_allocation(n_fft)
+    mask = CM.tx_mask(st.sym_len).astype(np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 2, 1, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True, active=active, tx_mask=mask.astype(np.float64))
+    lab, noise = O.gen_labels(osys, seed, cell, frame), O.gen_noise(osys, seed, cell, frame)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64),
+                     h[1].astype(np.complex128), float(snrs[0]), lab, noise, dump=True)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plan.set_allocation(active)
+        plan.set_tx_mask(mask)
+        assert plan.info()["waves_per_workgroup"] == S          # one symbol per wave
+        gc, gd = plan.dump_frame(cell, frame, *((lab, noise.astype(np.complex64)) if inject else ()))
+    assert np.array_equal(gd["labels_tx"], lab)
+    assert int(gc[1]) == int(oc[1]) and int(gc[3]) == int(oc[3])
+    for stage in ("X", "tx", "conv", "rx", "Y"):
+        assert _rel(gd[stage], od[stage]) < STAGE_RTOL, stage
+    _check_decisions(gd, od, gc, oc, k, active)
+    # independent restatement of the mask stage with numpy FFTs on the oracle's own symbols
+    rows = (np.fft.ifft(od["X"], axis=1)[:, (np.arange(st.sym_len) - st.cp) % n_fft]
+            * w_tx.astype(np.float64)[None, :])
+    filt = CM.dft_rc_filt(rows)
+    tx = np.zeros(st.frame_len(S), complex)
+    for s in range(S):
+        tx[s * st.stride:s * st.stride + st.sym_len] += filt[s]
+    assert _rel(od["tx"], tx) < 1e-7            # the mask handed to both is float32-rounded
+    assert _rel(gd["tx"], tx) < STAGE_RTOL
+
+
+def test_tx_mask_sweep_and_removal(channels):
+    S, seed, F, off, n_fft, k = 16, 13, 12, 5, 256, 4
+    st = W.make_structure("WOLA", n_fft, 24)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[8:10].astype(np.complex64)
+    snrs = np.array([5.0, 25.0], dtype=np.float32)
+    active = CM.half_band_allocation(n_fft)
+    mask = CM.tx_mask(st.sym_len)
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, seed=seed)
+    args = (w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128),
+            snrs.astype(np.float64), seed, off, F)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plain0 = plan.run(off, F)
+        plan.set_allocation(active)
+        plan.set_tx_mask(mask)
+        masked = plan.run(off, F)
+        plan.set_tx_mask(None)
+        alloc = plan.run(off, F)
+        plan.set_allocation(None)
+        plain1 = plan.run(off, F)
+    assert np.array_equal(plain0, plain1)                      # options leave no residue
+    want_m = O.run(_osys(st, k, S, 21, True, active=active, tx_mask=mask), *args)
+    want_a = O.run(_osys(st, k, S, 21, True, active=active), *args)
+    for got, want in ((masked, want_m), (alloc, want_a)):
+        assert np.array_equal(got[..., 1], want[..., 1])
+        bits = float(want[0, 0, 0, 1])
+        assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
+
+
+def test_tx_mask_limits(channels):
+    st = W.make_structure("WOLA", 1024, 32)
+    cfg = W.make_cfg(st, 2, 16, 21, 1, 1, 1)
+    with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), channels[:1].astype(np.complex64),
+                np.array([10.0], np.float32)) as plan:
+        with pytest.raises(W._lib.WofdmError) as e:
+            plan.set_tx_mask(CM.tx_mask(st.sym_len))
+        assert e.value.code == -2
+        assert plan.run(0, 2)[0, 0, 0, 1] == 2 * 15 * 1024 * 2     # still usable, unmasked
+
+
+def test_run_sim_mc_mirror(channels):
+    st = W.make_structure("wtx", 256, 16)
+    masked, plain = CM.run_sim_mc("wtx", 256, 16, W.tx_rc_window(st), W.rx_rc_window(st),
+                                  channels[:2], [0.0, 30.0], ensemble=30)
+    assert masked.shape == plain.shape == (1, 2, 2, 4)
+    assert (plain[..., 1] == 30 * 15 * 128 * 4).all() and (masked[..., 1] == plain[..., 1]).all()
+    ber_p, ber_m = plain[..., 0] / plain[..., 1], masked[..., 0] / masked[..., 1]
+    assert (ber_p[0, 0] > ber_p[0, 1]).all() and (ber_m[0, 0] > ber_m[0, 1]).all()
+    assert (ber_m[0, 1] < 0.1).all()

@@ -11,6 +11,7 @@ as ``wofdm_amd`` through the shim module at the repository root.
   interference closed-form ICI+ISI power of a structure (interf_power mirror, host numpy)
   window_design  interference Hessians + QP -> optimised windows (optimizers.py / window_optimization.m)
   timefreq     Tx-side PSD / out-of-band-radiation estimate (timefreq_simulation.py)
+  channel_mask main_channel_mask.m: half-band loading + spectral Tx mask (GPU: allocation / tx_mask)
   _lib         ctypes binding of libwofdm_hip.so (include/wofdm.h)
 """
 from . import variants  # noqa: F401
@@ -21,6 +22,7 @@ from . import driver  # noqa: F401
 from . import interference  # noqa: F401
 from . import window_design  # noqa: F401
 from . import timefreq  # noqa: F401
+from . import channel_mask  # noqa: F401
 from .simulation import (Plan, ber_for_window_file, error_rates, make_cfg,  # noqa: F401
                          results_from_counts, run_counts, run_counts_injected, run_simulation,
                          save_ber_results, simulation_fun, wOFDMSystem)

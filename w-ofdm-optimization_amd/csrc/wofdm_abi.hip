@@ -87,19 +87,52 @@ struct wofdm_plan {
     float2 *d_nscr = nullptr;          // unit-noise scratch rows, one per workgroup (large DFTs)
     uint64_t nscr_wgs = 0;
     wofdm_kparams base{};
-    wofdm_kernel_fn fn[WOFDM_VAR_COUNT][4] = {};
-    int var = WOFDM_VAR_PLAIN;         // kernel variant in use (wofdm_plan_set_allocation)
+    wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};   // kernels of the variant in use
+    int var = WOFDM_VAR_PLAIN;         // kernel variant in use (configure())
+    bool has_alloc = false, has_mask = false;
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
+    float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     int occ = 1, cus = 1, spw = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
 
+// Select the kernel variant from the plan's options and size everything that depends on it
+// (symbols per wave, LDS bytes, frame buffer length, occupancy).  Plan state changes only on success.
+int configure(wofdm_plan *pl)
+{
+    const geom &g = pl->g;
+    const int var = pl->has_mask ? WOFDM_VAR_TXMASK : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
+    const int spw = var == WOFDM_VAR_TXMASK ? 1 : wofdm_spw(g.N, g.S, g.B);
+    const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
+                         + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u);
+    if (lds > 160u * 1024u)
+        return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)", lds);
+    wofdm_kernel_fn fn[4];
+    for (int m = 0; m < 4; ++m) {
+        fn[m] = wofdm_select_kernel(g.N, g.k, spw, m, var);
+        if (!fn[m])
+            return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d bits_per_sc=%d variant %d%s", g.N, g.k,
+                        var, var == WOFDM_VAR_TXMASK ? " (the Tx mask needs n_fft <= 512)" : "");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn[m]),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / spw, lds));
+    if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
+    const int fbuf = wofdm_fbuf_len(g.N, g.T, spw);
+    HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
+    for (int m = 0; m < 4; ++m) pl->fn[m] = fn[m];
+    pl->var = var; pl->spw = spw; pl->occ = occ; pl->base.lds_bytes = lds;
+    return WOFDM_OK;
+}
+
 int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, int force_grid,
            hipStream_t stream)
 {
-    wofdm_kernel_fn fn = pl->fn[pl->var][mode];
+    wofdm_kernel_fn fn = pl->fn[mode];
     if (!fn) return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d", pl->g.N);
     if (total_items == 0) return WOFDM_OK;
     uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
@@ -114,7 +147,9 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         pl->nscr_wgs = grid;
     }
     kp.noise_scratch = pl->d_nscr;
-    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask};
+    kp.lds_bytes = pl->base.lds_bytes;
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask,
+                    &pl->d_tmask};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
     return WOFDM_OK;
@@ -206,42 +241,23 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     geo[WOFDM_G_DELTA] = g.delta; geo[WOFDM_G_GAMMA] = g.gamma; geo[WOFDM_G_KAPPA] = g.kappa;
     geo[WOFDM_G_L] = g.L; geo[WOFDM_G_P] = g.P; geo[WOFDM_G_B] = g.B; geo[WOFDM_G_T] = g.T;
     geo[WOFDM_G_NL] = g.NL; geo[WOFDM_G_NSNR] = cfg->n_snr; geo[WOFDM_G_NCH] = cfg->n_channels;
-    pl->spw = wofdm_spw(g.N, g.S, g.B);
-    geo[WOFDM_G_FBUF] = wofdm_fbuf_len(g.N, g.T, pl->spw);
+    geo[WOFDM_G_FBUF] = 0;                       // set by configure()
     geo[WOFDM_G_NACT] = g.N;
     PLAN_TRY(hipMalloc(&pl->d_geo, sizeof geo));
     PLAN_TRY(hipMemcpy(pl->d_geo, geo, sizeof geo, hipMemcpyHostToDevice));
 
     wofdm_kparams &kp = pl->base;
     kp.n_cells = pl->n_cells; kp.first_cell = 0; kp.inject_base_cell = 0;
-    kp.lds_bytes = wofdm_lds_bytes(g.N, g.T, pl->spw);
     kp.seed_lo = (uint32_t)cfg->seed; kp.seed_hi = (uint32_t)(cfg->seed >> 32);
 
     hipDeviceProp_t prop;
     PLAN_TRY(hipGetDeviceProperties(&prop, device));
     pl->cus = prop.multiProcessorCount;
-    if (kp.lds_bytes > 160u * 1024u) {
+    if ((rc = configure(pl)) != WOFDM_OK) {
         wofdm_plan_destroy(pl);
-        return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)",
-                    kp.lds_bytes);
+        return rc;
     }
-    for (int v = 0; v < WOFDM_VAR_COUNT; ++v)
-        for (int m = 0; m < 4; ++m) {
-            pl->fn[v][m] = wofdm_select_kernel(g.N, g.k, pl->spw, m, v);
-            if (!pl->fn[v][m]) continue;
-            PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl->fn[v][m]),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kp.lds_bytes));
-        }
-    int occ = 0;
-    PLAN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(pl->fn[WOFDM_VAR_PLAIN][WOFDM_MODE_GEN]), 64 * g.S / pl->spw,
-        kp.lds_bytes));
-    if (occ < 1) {
-        wofdm_plan_destroy(pl);
-        return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", kp.lds_bytes);
-    }
-    pl->occ = occ;
+    const int occ = pl->occ;
     if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
         pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
         PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
@@ -262,6 +278,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_geo) (void)hipFree(pl->d_geo);
     if (pl->d_nscr) (void)hipFree(pl->d_nscr);
     if (pl->d_amask) (void)hipFree(pl->d_amask);
+    if (pl->d_tmask) (void)hipFree(pl->d_tmask);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
@@ -286,9 +303,45 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
         if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->d_amask, words.data(), (size_t)NQ * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    pl->var = (active && nact < N) ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN;
+    if (!active && pl->d_amask) HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)NQ * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_NACT, &nact, sizeof(int), hipMemcpyHostToDevice));
-    return WOFDM_OK;
+    pl->has_alloc = active && nact < N;
+    return configure(pl);
+}
+
+int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
+{
+    if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
+    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!mask) {
+        pl->has_mask = false;
+        return configure(pl);
+    }
+    // impulse response of the mask: g = IDFT_{2P-1}(mask), in double on the host (complex in
+    // general: main_channel_mask.m's centred raised cosine is not even around bin 0 when P is odd)
+    const int Lm = 2 * pl->g.P - 1, NQ = pl->g.N / 4;
+    std::vector<float2> gtd((size_t)Lm);
+    for (int n = 0; n < Lm; ++n) {
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k < Lm; ++k) {
+            const double a = 2.0 * M_PI * (double)(((long long)k * n) % Lm) / (double)Lm;
+            re += (double)mask[k] * std::cos(a);
+            im += (double)mask[k] * std::sin(a);
+        }
+        gtd[(size_t)n] = make_float2((float)(re / Lm), (float)(im / Lm));
+    }
+    if (!pl->d_tmask) HIP_TRY(hipMalloc(&pl->d_tmask, (size_t)Lm * sizeof(float2)));
+    HIP_TRY(hipMemcpy(pl->d_tmask, gtd.data(), (size_t)Lm * sizeof(float2), hipMemcpyHostToDevice));
+    if (!pl->d_amask) {        // the mask kernels always read an allocation word
+        HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)NQ * sizeof(uint32_t)));
+    }
+    const bool had = pl->has_mask;
+    pl->has_mask = true;
+    const int rc = configure(pl);
+    if (rc != WOFDM_OK) pl->has_mask = had;
+    return rc;
 }
 
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])

@@ -88,10 +88,19 @@ static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
 // constants travel as separate noalias arguments so that uniform reads become scalar loads:
 // w_tx[pairs][P], w_rx[pairs][N+delta], h[n_ch][WOFDM_LT] zero padded, noise_lin[n_snr]
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
-                                const float *, const int *, const uint32_t *);
+                                const float *, const int *, const uint32_t *, const float2 *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
-// kernel variants: every subcarrier loaded / a subcarrier allocation mask
-enum { WOFDM_VAR_PLAIN = 0, WOFDM_VAR_ALLOC = 1, WOFDM_VAR_COUNT };
+// kernel variants: every subcarrier loaded / a subcarrier allocation mask / allocation + per-symbol
+// spectral Tx mask (one symbol per wave, n_fft <= WOFDM_TXMASK_MAX_N: the mask table needs LDS)
+enum { WOFDM_VAR_PLAIN = 0, WOFDM_VAR_ALLOC = 1, WOFDM_VAR_TXMASK = 2, WOFDM_VAR_COUNT };
+#define WOFDM_TXMASK_MAX_N 512
+// bytes of LDS the (complex) Tx mask table takes behind the frame buffer (mask_geo in
+// wofdm_kernel.hip)
+static inline unsigned wofdm_txmask_lds_bytes(int n_fft)
+{
+    const int lmax = 2 * (n_fft + 128) - 1, no = (lmax + 63) / 64, mb = 4;
+    return 8u * (unsigned)((n_fft + 128 + 2 * mb) + 64 * no + mb);
+}
 // one translation unit per DFT length (wofdm_kernel.hip with -DWOFDM_TU_N=<N>)
 wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode, int var);
 wofdm_kernel_fn wofdm_select_kernel_n128(int bits_per_sc, int spw, int mode, int var);

@@ -381,6 +381,18 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 
 __device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
 
+// Tx mask stage (VAR 2): a lane owns NO consecutive outputs of the 2P-1 <= 2(N+128)-1 samples of
+// the filtered symbol; the inputs are walked MB at a time.  rg[] is the periodic extension of the
+// mask's impulse response (complex: the reference's mask is not even around bin 0 when P is odd),
+// RG_OFF entries of history in front.
+template <int N> struct mask_geo {
+    static constexpr int LMAX = 2 * (N + wofdm_lds<N>::CPCS_MAX) - 1;
+    static constexpr int NO = (LMAX + 63) / 64;
+    static constexpr int MB = 4;
+    static constexpr int RG_OFF = N + wofdm_lds<N>::CPCS_MAX + 2 * MB;
+    static constexpr int RG_LEN = RG_OFF + 64 * NO + MB;
+};
+
 // FIR outputs per lane: one wave covers SPW symbols = SPW*B consecutive samples.  For SPW = 2
 // the count is even and every lane starts on an even sample, so its unit noise is exactly
 // RB/2 Philox blocks (2.5 per symbol instead of 3).
@@ -402,15 +414,17 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 
 // VAR: 0 = every subcarrier loaded (main_BER_calculation.m); 1 = subcarrier allocation: only the
 // bins flagged in g_amask carry data, the others transmit zero and are not counted
-// (main_channel_mask.m:387-390, 367-371)
+// (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
+// dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int SPW, bool INJECT, bool DUMP, int VAR>
 __global__ void __launch_bounds__(1024 / SPW, WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
-                    const uint32_t *__restrict__ g_amask)
+                    const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask)
 {
-    constexpr bool ALLOC = VAR >= 1;
+    constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2;
+    static_assert(!TXMASK || SPW == 1, "the Tx mask stage runs one symbol per wave");
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
     constexpr bool FULL = geo<N>::FULL;
@@ -459,6 +473,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const uint32_t gi = (uint32_t)tid >> hb, gq = (uint32_t)tid & (uint32_t)mm;
         const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2)), lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
         qlut[tid] = mk((float)(2 * li - mm), (float)(mm - 2 * lq)) * qs;
+    }
+    // Tx mask: periodic extension of the mask's impulse response behind the frame buffer,
+    // rg[t] = g[(t - RG_OFF) mod (2P-1)], so that the stage below indexes it without a modulo
+    v2f *rg = fbuf + gm[WOFDM_G_FBUF];
+    if constexpr (TXMASK) {
+        const int Lm = 2 * gm[WOFDM_G_P] - 1;
+        for (int t = tid; t < mask_geo<N>::RG_LEN; t += blockDim.x) {
+            int kk = (t - mask_geo<N>::RG_OFF) % Lm;
+            if (kk < 0) kk += Lm;
+            rg[t] = ldg2(g_tmask + kk);
+        }
     }
     __syncthreads();
 
@@ -676,6 +701,70 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         };
         if (rho < gq[WOFDM_G_BETA]) tx_write(std::true_type{});
         else tx_write(std::false_type{});
+
+        if constexpr (TXMASK) {
+            // dft_rc_filt (main_channel_mask.m:398-417): every windowed symbol x (P samples,
+            // zero-padded to 2P-1) is circularly convolved with the mask's impulse response g:
+            // y[n] = sum_m g[(n - m) mod (2P-1)] x[m].  y[0..P) replaces the symbol, y[P..2P-1)
+            // is added to the FIRST P-1 samples of the next symbol's row (m:411-415), the last
+            // symbol's spill is dropped.  Lane l owns NO consecutive outputs; the table values
+            // slide through registers (one LDS read per input sample and lane).
+            constexpr int NO = mask_geo<N>::NO, MB = mask_geo<N>::MB, OFF = mask_geo<N>::RG_OFF;
+            const int P = gq[WOFDM_G_P];
+            const int s = s0;
+            v2f *fb = fbw;
+            const bool last = s == S - 1;
+            // the symbol's row: samples [0, B) in the frame slice, [B, P) in the tail buffer
+            // (the last symbol keeps them in the frame buffer)
+            const v2f *xt = last ? fb + B : tailb + s * L::TAIL_MAX;
+            wave_sync();
+            v2f y[NO];
+#pragma unroll
+            for (int i = 0; i < NO; ++i) y[i] = mk(0.f, 0.f);
+            for (int m0 = 0; m0 < P; m0 += MB) {
+                v2f win[NO + MB - 1];
+                const v2f *rb = rg + (OFF + lane * NO - m0 - (MB - 1));
+#pragma unroll
+                for (int j = 0; j < NO + MB - 1; ++j) win[j] = rb[j];
+#pragma unroll
+                for (int mm = 0; mm < MB; ++mm) {
+                    const int m = m0 + mm;
+                    v2f xm = mk(0.f, 0.f);
+                    if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
+                    const v2f xn = mk(-xm.y, xm.y);
+#pragma unroll
+                    for (int i = 0; i < NO; ++i) {
+                        const v2f gg = win[i - mm + MB - 1];        // y += x g (complex)
+                        y[i] = __builtin_elementwise_fma(xm.xx, gg, y[i]);
+                        y[i] = __builtin_elementwise_fma(xn, gg.yx, y[i]);
+                    }
+                }
+            }
+            wave_sync();
+            // own row <- y[0..P)
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const int n = lane * NO + i;
+                if (n < P) {
+                    if (n < B || last) fb[n] = y[i];
+                    else tailb[s * L::TAIL_MAX + (n - B)] = y[i];
+                }
+            }
+            __syncthreads();
+            // next symbol's row += y[P..2P-1)
+            if (!last) {
+                const bool nlast = s + 1 == S - 1;
+                v2f *fn = fb + B;
+#pragma unroll
+                for (int i = 0; i < NO; ++i) {
+                    const int j = lane * NO + i - P;
+                    if (j >= 0 && j < P - 1) {
+                        v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * L::TAIL_MAX + (j - B);
+                        *dst = *dst + y[i];
+                    }
+                }
+            }
+        }
         }
         STAMP(0);
         __syncthreads();                                                     // ---- barrier 1
@@ -962,6 +1051,9 @@ template <int N, int K, int SPW> wofdm_kernel_fn pick_var(int mode, int var)
     switch (var) {
     case WOFDM_VAR_PLAIN: return pick_mode<N, K, SPW, WOFDM_VAR_PLAIN>(mode);
     case WOFDM_VAR_ALLOC: return pick_mode<N, K, SPW, WOFDM_VAR_ALLOC>(mode);
+    case WOFDM_VAR_TXMASK:
+        if constexpr (SPW == 1 && N <= WOFDM_TXMASK_MAX_N) return pick_mode<N, K, SPW, WOFDM_VAR_TXMASK>(mode);
+        break;
     }
     return nullptr;
 }

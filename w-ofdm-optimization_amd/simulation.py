@@ -102,6 +102,15 @@ class Plan:
         _lib.check(self.lib.wofdm_plan_set_allocation(self._h_plan, a.ctypes.data))
         self.n_active = int(a.sum())
 
+    def set_tx_mask(self, mask):
+        """Per-symbol spectral Tx mask (``wofdm_plan_set_tx_mask``): ``mask`` [2P-1] DFT-domain
+        gains in natural bin order (main_channel_mask.m:398-417); None removes it."""
+        if mask is None:
+            _lib.check(self.lib.wofdm_plan_set_tx_mask(self._h_plan, None))
+            return
+        m = _lib.f32(np.asarray(mask).reshape(-1), (2 * self.cfg.sym_len - 1,))
+        _lib.check(self.lib.wofdm_plan_set_tx_mask(self._h_plan, m.ctypes.data))
+
     def new_counts(self):
         """Zeroed device counter tensor [pairs][n_snr][n_channels][4] (int64 bit pattern of the
         kernel's uint64 counters; torch is only the allocator here)."""
