@@ -132,8 +132,10 @@ MASK_CASES = [("wtx", 256, 32, 4), ("WOLA", 256, 22, 4), ("CPW", 64, 16, 2), ("C
 
 
 @pytest.mark.parametrize("system,n_fft,cp,k", MASK_CASES)
-@pytest.mark.parametrize("inject", [False, True])
-def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject):
+@pytest.mark.parametrize("inject,direct", [(False, False), (True, False), (False, True)])
+def test_tx_mask_one_frame_stage_by_stage(channels, monkeypatch, system, n_fft, cp, k, inject, direct):
+    # direct: force the direct-form convolution where the fast-convolution form would be used
+    monkeypatch.setenv("WOFDM_TXMASK_DIRECT", "1" if direct else "0")
     S, seed, frame, cell = 16, 9, 777, 1
     st = W.make_structure(system, n_fft, cp)
     w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
@@ -149,7 +151,14 @@ def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject
     with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
         plan.set_allocation(active)
         plan.set_tx_mask(mask)
-        assert plan.info()["waves_per_workgroup"] == S          # one symbol per wave
+        info = plan.info()
+        assert info["waves_per_workgroup"] == S                 # one symbol per wave
+        plan.set_tx_mask(None)
+        base = plan.info()["lds_bytes"] if S % 2 else None       # (even S: plain runs 2 symbols/wave)
+        plan.set_tx_mask(mask)
+        fft_form = n_fft <= 256 and 3 * st.sym_len - 2 <= 1024 and not direct
+        # fast-convolution form: 1024 twiddles + 8 scratch rows of 1024 points behind the frame
+        assert (info["lds_bytes"] >= 9 * 1024 * 8) == fft_form or n_fft == 512
         gc, gd = plan.dump_frame(cell, frame, *((lab, noise.astype(np.complex64)) if inject else ()))
     assert np.array_equal(gd["labels_tx"], lab)
     assert int(gc[1]) == int(oc[1]) and int(gc[3]) == int(oc[3])
@@ -167,8 +176,9 @@ def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject
     assert _rel(gd["tx"], tx) < STAGE_RTOL
 
 
-def test_tx_mask_sweep_and_removal(channels):
-    S, seed, F, off, n_fft, k = 16, 13, 12, 5, 256, 4
+@pytest.mark.parametrize("S", [16, 5, 11])
+def test_tx_mask_sweep_and_removal(channels, S):
+    seed, F, off, n_fft, k = 13, 12, 5, 256, 4
     st = W.make_structure("WOLA", n_fft, 24)
     w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
     h = channels[8:10].astype(np.complex64)

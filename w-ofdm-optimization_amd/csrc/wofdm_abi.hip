@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -90,8 +91,10 @@ struct wofdm_plan {
     wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};   // kernels of the variant in use
     int var = WOFDM_VAR_PLAIN;         // kernel variant in use (configure())
     bool has_alloc = false, has_mask = false;
+    bool force_direct_mask = false;    // WOFDM_TXMASK_DIRECT=1 (developer switch): never the FFT form
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
+    float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
     int occ = 1, cus = 1, spw = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -103,10 +106,15 @@ namespace {
 int configure(wofdm_plan *pl)
 {
     const geom &g = pl->g;
-    const int var = pl->has_mask ? WOFDM_VAR_TXMASK : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
-    const int spw = var == WOFDM_VAR_TXMASK ? 1 : wofdm_spw(g.N, g.S, g.B);
+    // the mask runs as fast convolution where its transform length allows, else in direct form
+    const bool fft_ok = g.N <= WOFDM_TXFFT_MAX_N && 3 * g.P - 2 <= WOFDM_TXFFT_LEN && !pl->force_direct_mask;
+    const int var = pl->has_mask ? (fft_ok ? WOFDM_VAR_TXFFT : WOFDM_VAR_TXMASK)
+                                 : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
+    const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
+    const int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
-                         + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u);
+                         + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
+                         + (var == WOFDM_VAR_TXFFT ? wofdm_txfft_lds_bytes() : 0u);
     if (lds > 160u * 1024u)
         return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)", lds);
     wofdm_kernel_fn fn[4];
@@ -114,7 +122,7 @@ int configure(wofdm_plan *pl)
         fn[m] = wofdm_select_kernel(g.N, g.k, spw, m, var);
         if (!fn[m])
             return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d bits_per_sc=%d variant %d%s", g.N, g.k,
-                        var, var == WOFDM_VAR_TXMASK ? " (the Tx mask needs n_fft <= 512)" : "");
+                        var, masked ? " (the Tx mask needs n_fft <= 512)" : "");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn[m]),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -148,8 +156,8 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     }
     kp.noise_scratch = pl->d_nscr;
     kp.lds_bytes = pl->base.lds_bytes;
-    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask,
-                    &pl->d_tmask};
+    float2 *tm = pl->var == WOFDM_VAR_TXFFT ? pl->d_tspec : pl->d_tmask;
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
     return WOFDM_OK;
@@ -279,6 +287,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_nscr) (void)hipFree(pl->d_nscr);
     if (pl->d_amask) (void)hipFree(pl->d_amask);
     if (pl->d_tmask) (void)hipFree(pl->d_tmask);
+    if (pl->d_tspec) (void)hipFree(pl->d_tspec);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
@@ -333,11 +342,46 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
     }
     if (!pl->d_tmask) HIP_TRY(hipMalloc(&pl->d_tmask, (size_t)Lm * sizeof(float2)));
     HIP_TRY(hipMemcpy(pl->d_tmask, gtd.data(), (size_t)Lm * sizeof(float2), hipMemcpyHostToDevice));
+    {
+        // fast-convolution spectrum: FFT_MF of gt[t] = g[(t - (P-1)) mod (2P-1)], t < 3P-2, with the
+        // 1/MF of the inverse transform folded in (wofdm_kernel.hip, TXFFT)
+        const int MF = WOFDM_TXFFT_LEN, P = pl->g.P, G = 3 * P - 2;
+        std::vector<float2> spec((size_t)MF, make_float2(0.f, 0.f));
+        if (G <= MF) {
+            std::vector<double> gr((size_t)G), gi((size_t)G), cw((size_t)MF), sw((size_t)MF);
+            for (int t = 0; t < G; ++t) {
+                const int kk = ((t - (P - 1)) % Lm + Lm) % Lm;
+                double re = 0.0, im = 0.0;          // g in double again (gtd is rounded to float)
+                for (int k = 0; k < Lm; ++k) {
+                    const double a = 2.0 * M_PI * (double)(((long long)k * kk) % Lm) / (double)Lm;
+                    re += (double)mask[k] * std::cos(a);
+                    im += (double)mask[k] * std::sin(a);
+                }
+                gr[(size_t)t] = re / Lm; gi[(size_t)t] = im / Lm;
+            }
+            for (int q = 0; q < MF; ++q) {
+                cw[(size_t)q] = std::cos(2.0 * M_PI * q / MF); sw[(size_t)q] = -std::sin(2.0 * M_PI * q / MF);
+            }
+            for (int f = 0; f < MF; ++f) {
+                double re = 0.0, im = 0.0;
+                for (int t = 0; t < G; ++t) {
+                    const int q = (int)(((long long)f * t) % MF);
+                    re += gr[(size_t)t] * cw[(size_t)q] - gi[(size_t)t] * sw[(size_t)q];
+                    im += gr[(size_t)t] * sw[(size_t)q] + gi[(size_t)t] * cw[(size_t)q];
+                }
+                spec[(size_t)f] = make_float2((float)(re / MF), (float)(im / MF));
+            }
+        }
+        if (!pl->d_tspec) HIP_TRY(hipMalloc(&pl->d_tspec, (size_t)MF * sizeof(float2)));
+        HIP_TRY(hipMemcpy(pl->d_tspec, spec.data(), (size_t)MF * sizeof(float2), hipMemcpyHostToDevice));
+    }
     if (!pl->d_amask) {        // the mask kernels always read an allocation word
         HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
         HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)NQ * sizeof(uint32_t)));
     }
     const bool had = pl->has_mask;
+    const char *fd = std::getenv("WOFDM_TXMASK_DIRECT");
+    pl->force_direct_mask = fd && fd[0] == '1';
     pl->has_mask = true;
     const int rc = configure(pl);
     if (rc != WOFDM_OK) pl->has_mask = had;

@@ -92,8 +92,18 @@ typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, con
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
 // kernel variants: every subcarrier loaded / a subcarrier allocation mask / allocation + per-symbol
 // spectral Tx mask (one symbol per wave, n_fft <= WOFDM_TXMASK_MAX_N: the mask table needs LDS)
-enum { WOFDM_VAR_PLAIN = 0, WOFDM_VAR_ALLOC = 1, WOFDM_VAR_TXMASK = 2, WOFDM_VAR_COUNT };
+// (direct form, g_tmask = impulse response) / the same as fast convolution (g_tmask = spectrum; n_fft
+// <= WOFDM_TXFFT_MAX_N and 3P-2 <= WOFDM_TXFFT_LEN)
+enum { WOFDM_VAR_PLAIN = 0, WOFDM_VAR_ALLOC = 1, WOFDM_VAR_TXMASK = 2, WOFDM_VAR_TXFFT = 3, WOFDM_VAR_COUNT };
 #define WOFDM_TXMASK_MAX_N 512
+#define WOFDM_TXFFT_MAX_N 256
+#define WOFDM_TXFFT_LEN 1024
+#define WOFDM_TXFFT_SLOTS 8
+// LDS behind the frame buffer in the FFT form: twiddles + scratch rows
+static inline unsigned wofdm_txfft_lds_bytes(void)
+{
+    return 8u * (unsigned)(WOFDM_TXFFT_LEN * (1 + WOFDM_TXFFT_SLOTS));
+}
 // bytes of LDS the (complex) Tx mask table takes behind the frame buffer (mask_geo in
 // wofdm_kernel.hip)
 static inline unsigned wofdm_txmask_lds_bytes(int n_fft)

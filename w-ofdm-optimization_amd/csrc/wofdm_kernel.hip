@@ -393,6 +393,11 @@ template <int N> struct mask_geo {
     static constexpr int RG_LEN = RG_OFF + 64 * NO + MB;
 };
 
+// Tx mask, FFT form (VAR 3, n_fft <= 256): MF-point transforms, SLOTS scratch rows
+struct maskfft_geo {
+    static constexpr int MF = WOFDM_TXFFT_LEN, SLOTS = WOFDM_TXFFT_SLOTS;
+};
+
 // FIR outputs per lane: one wave covers SPW symbols = SPW*B consecutive samples.  For SPW = 2
 // the count is even and every lane starts on an even sample, so its unit noise is exactly
 // RB/2 Philox blocks (2.5 per symbol instead of 3).
@@ -423,8 +428,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
                     const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask)
 {
-    constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2;
-    static_assert(!TXMASK || SPW == 1, "the Tx mask stage runs one symbol per wave");
+    constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
+    static_assert(!(TXMASK || TXFFT) || SPW == 1, "the Tx mask stage runs one symbol per wave");
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
     constexpr bool FULL = geo<N>::FULL;
@@ -485,6 +490,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             rg[t] = ldg2(g_tmask + kk);
         }
     }
+    // Tx mask, FFT form: twiddles of the MF-point transforms and MF_SLOTS scratch rows behind
+    // the frame buffer
+    v2f *mtw = fbuf + gm[WOFDM_G_FBUF];
+    v2f *mscr = mtw + maskfft_geo::MF;
+    if constexpr (TXFFT) fill_twiddles<maskfft_geo::MF>(mtw, tid, (int)blockDim.x);
     __syncthreads();
 
     // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
@@ -702,6 +712,69 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (rho < gq[WOFDM_G_BETA]) tx_write(std::true_type{});
         else tx_write(std::false_type{});
 
+        if constexpr (TXFFT) {
+            // dft_rc_filt as fast convolution.  y[n] = sum_m g[(n - m) mod (2P-1)] x[m], n < 2P-1,
+            // is the linear convolution of x with gt[t] = g[(t - (P-1)) mod (2P-1)], t < 3P-2, read
+            // at j = n + P - 1; an MF-point circular convolution gives exactly those samples when
+            // 3P - 2 <= MF (only j < P-1 alias).  g_tmask holds FFT_MF(gt) / MF.  The MF-point
+            // scratch rows do not fit for all 16 waves at once: the waves take turns, MF_SLOTS at a time.
+            constexpr int MF = maskfft_geo::MF, MQ = MF / 4, MBPL = MQ / 64, SLOTS = maskfft_geo::SLOTS;
+            const int P = gq[WOFDM_G_P];
+            const int s = s0;
+            v2f *fb = fbw;
+            const bool last = s == S - 1;
+            const v2f *xt = last ? fb + B : tailb + s * L::TAIL_MAX;
+            v2f *scr = mscr + (wv % SLOTS) * MF;
+            v2f y[1][MBPL][4];
+            wave_sync();
+            for (int round = 0; round * SLOTS < S; ++round) {
+                if (wv / SLOTS == round) {
+#pragma unroll
+                    for (int q = 0; q < MBPL; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = lane + 64 * q + r * MQ;
+                            v2f xm = mk(0.f, 0.f);
+                            if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
+                            y[0][q][r] = xm;
+                        }
+                    fft_wave<MF, -1, 1>(y, scr, 0, mtw, lane);
+#pragma unroll
+                    for (int q = 0; q < MBPL; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            y[0][q][r] = cmul(y[0][q][r], ldg2(g_tmask + lane + 64 * q + r * MQ));
+                    fft_wave<MF, +1, 1>(y, scr, 0, mtw, lane);
+                }
+                __syncthreads();
+            }
+            // own row <- y[0..P): element j = n + P - 1
+#pragma unroll
+            for (int q = 0; q < MBPL; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = lane + 64 * q + r * MQ - (P - 1);
+                    if (n >= 0 && n < P) {
+                        if (n < B || last) fb[n] = y[0][q][r];
+                        else tailb[s * L::TAIL_MAX + (n - B)] = y[0][q][r];
+                    }
+                }
+            __syncthreads();
+            if (!last) {
+                const bool nlast = s + 1 == S - 1;
+                v2f *fn = fb + B;
+#pragma unroll
+                for (int q = 0; q < MBPL; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = lane + 64 * q + r * MQ - (P - 1) - P;
+                        if (j >= 0 && j < P - 1) {
+                            v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * L::TAIL_MAX + (j - B);
+                            *dst = *dst + y[0][q][r];
+                        }
+                    }
+            }
+        }
         if constexpr (TXMASK) {
             // dft_rc_filt (main_channel_mask.m:398-417): every windowed symbol x (P samples,
             // zero-padded to 2P-1) is circularly convolved with the mask's impulse response g:
@@ -1053,6 +1126,9 @@ template <int N, int K, int SPW> wofdm_kernel_fn pick_var(int mode, int var)
     case WOFDM_VAR_ALLOC: return pick_mode<N, K, SPW, WOFDM_VAR_ALLOC>(mode);
     case WOFDM_VAR_TXMASK:
         if constexpr (SPW == 1 && N <= WOFDM_TXMASK_MAX_N) return pick_mode<N, K, SPW, WOFDM_VAR_TXMASK>(mode);
+        break;
+    case WOFDM_VAR_TXFFT:
+        if constexpr (SPW == 1 && N <= WOFDM_TXFFT_MAX_N) return pick_mode<N, K, SPW, WOFDM_VAR_TXFFT>(mode);
         break;
     }
     return nullptr;
