@@ -1,0 +1,74 @@
+"""Randomised geometry sweep on the GPU against the oracle: tails other than the reference's 8/10,
+short channels, odd frame lengths, prefix lengths up to the kernel's limits, random subcarrier
+allocations and (where supported) the spectral Tx mask -- the corners the fixed cases leave out.
+Deterministic (seeded); every case is a 2-cell sweep of a few frames."""
+import numpy as np
+import pytest
+
+import wofdm_amd as W
+from oracle import oracle as O
+from wofdm_amd import channel_mask as CM
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n_cases=120, seed=20240607):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n_cases:
+        system = W.SYSTEMS[rs.randint(len(W.SYSTEMS))]
+        n_fft = int(rs.choice([64, 128, 256, 512, 1024], p=[.25, .2, .3, .15, .1]))
+        k = int(rs.choice([2, 4, 6]))
+        S = int(rs.choice([2, 3, 4, 7, 8, 9, 13, 16]))
+        btx = int(rs.choice([2, 4, 6, 8, 12, 16])) if system in W.variants.TX_WINDOWED else 0
+        brx = int(rs.choice([2, 4, 10, 16, 32])) if system in W.variants.RX_WINDOWED else 0
+        cp = int(rs.randint(max(btx, brx, 4), 65))
+        taps = int(rs.choice([1, 5, 21]))
+        try:
+            st = W.make_structure(system, n_fft, cp, btx, brx)
+        except (AssertionError, ValueError):
+            continue
+        if st.prefix_rm < 0 or st.cp + st.cs > 128 or st.stride - n_fft > 64:
+            continue
+        opts = int(rs.choice([0, 0, 1, 2]))               # 0 plain, 1 allocation, 2 allocation + mask
+        if opts == 2 and n_fft > 512:
+            opts = 1
+        out.append((system, n_fft, k, S, btx, brx, cp, taps, opts, int(rs.randint(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("system,n_fft,k,S,btx,brx,cp,taps,opts,seed", _cases())
+def test_random_geometry(channels, system, n_fft, k, S, btx, brx, cp, taps, opts, seed):
+    rs = np.random.RandomState(seed)
+    st = W.make_structure(system, n_fft, cp, btx, brx)
+    xt = np.r_[1.0, np.sort(rs.uniform(.05, .95, btx))[::-1]] if btx else np.ones(1)
+    xr = np.r_[1.0, np.sort(rs.uniform(.05, .45, brx // 2))[::-1]] if brx else np.ones(1)
+    w_tx = (W.expand_tx_window(st, xt) if btx else np.ones(st.sym_len)).astype(np.float32)
+    w_rx = (W.expand_rx_window(st, xr) if brx else np.ones(st.rx_win_len)).astype(np.float32)
+    h = channels[rs.randint(90):][:2, :taps].astype(np.complex64)
+    h[:, 0] += 0.5                                        # keep short channels away from deep nulls
+    snrs = np.array([rs.uniform(0, 12), rs.uniform(18, 35)], dtype=np.float32)
+    matlab = bool(rs.randint(2))
+    F, off = 3, int(rs.randint(1 << 20))
+    active = (rs.rand(n_fft) < 0.55) if opts else None
+    if active is not None:
+        active[rs.randint(n_fft)] = True
+    mask = CM.tx_mask(st.sym_len, roll_off=int(rs.choice([4, 10, 20]))) if opts == 2 else None
+    cfg = W.make_cfg(st, k, S, taps, 2, 2, 1, noise_before_truncate=matlab, seed=seed)
+    osys = O.make_sys(n_fft, k, S, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm, st.circ_shift,
+                      taps, 1 if matlab else 0, active=active,
+                      tx_mask=None if mask is None else mask.astype(np.float32).astype(np.float64))
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        if active is not None:
+            plan.set_allocation(active)
+        if mask is not None:
+            plan.set_tx_mask(mask)
+        got = plan.run(off, F)
+    want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128),
+                 snrs.astype(np.float64), seed, off, F)
+    nact = n_fft if active is None else int(active.sum())
+    assert np.array_equal(got[..., 1], want[..., 1]) and got[0, 0, 0, 1] == F * (S - 1) * nact * k
+    assert np.array_equal(got[..., 3], want[..., 3])
+    tol = max(3, 2e-4 * float(want[0, 0, 0, 1]))
+    assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= tol).all(), (got[..., 0], want[..., 0])
+    assert (np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)) <= tol).all()
