@@ -687,7 +687,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int s = s0 + u;
                 v2f *fb = fbw + u * B;
                 const int Bs = (s == S - 1) ? 0x3fffffff : B;
-                const int Dt = (int)(tailb + s * L::TAIL_MAX - (fb + B));
+                // tailb + s TAIL_MAX - (fb + B) in v2f units, from the LDS offsets (a pointer
+                // difference would be taken on 64-bit generic addresses)
+                const int Dt = (L::off_tail - L::off_fbuf) / 8 + s * L::TAIL_MAX - (LT - 1) - (s + 1) * B;
 #pragma unroll
                 for (int q = 0; q < BPL; ++q) {
                     const int j = lane + 64 * q;
