@@ -65,8 +65,9 @@ int check_cfg(const wofdm_cfg *c, geom *g)
     if (g->B != N + g->delta + g->gamma)
         return fail(WOFDM_E_INVALID, "n_fft+cp+cs-tail_tx (%d) != n_fft+tail_rx+prefix_rm (%d)",
                     g->B, N + g->delta + g->gamma);
-    if (g->mu + g->rho > 128 || g->beta > 16 || g->delta > 64)
-        return fail(WOFDM_E_UNSUPPORTED, "kernel limits: cp+cs <= 128, tail_tx <= 16, tail_rx <= 64");
+    if (g->mu + g->rho > wofdm_cpcs_max(N) || g->beta > 16 || g->delta > 64)
+        return fail(WOFDM_E_UNSUPPORTED, "kernel limits: cp+cs <= %d, tail_tx <= 16, tail_rx <= 64",
+                    wofdm_cpcs_max(N));
     if (g->B > 64 * wofdm_rb(N))
         return fail(WOFDM_E_UNSUPPORTED, "cp+cs-tail_tx=%d exceeds the 64 samples the kernel's "
                     "FIR tiling allows", g->B - N);

@@ -16,18 +16,22 @@ struct wofdm_kdump {          // device pointers, all may be null
 // LDS carve: fixed-size regions first (compile-time offsets), the frame buffer last.
 //   tw    float2[N]          twiddles exp(-2 pi i m / N)
 //   g     float2[N]          pilot equaliser X0/Y0
-//   sums  float [32]         per-wave signal / noise power partials
-//   wtx   float [N + 128]    Tx window / N      (needs cp + cs <= 128)
+//   sums  float [2][32]      per-wave signal / noise power partials, double-buffered by frame parity
+//   flags int   [32]         [w] = last loop iteration whose phase A wave w has finished,
+//                            [16] = last iteration whose pilot equaliser G is published
+//   wtx   float [N + CPCS]   Tx window / N      (needs cp + cs <= CPCS_MAX = 128; 64 at N = 1024,
+//                            where the frame buffer leaves no room for more anyway)
 //   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)
 //   tail  float2[16][16]     fall tails         (needs tail_tx <= 16)
 //   lut   float2[64]         QAM constellation by label
 //   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
 template <int N> struct wofdm_lds {
-    static constexpr int TAIL_MAX = 16, CPCS_MAX = 128, TAILRX_MAX = 64;
+    static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
     static constexpr int off_g = off_tw + 8 * N;
     static constexpr int off_sums = off_g + 8 * N;
-    static constexpr int off_wtx = off_sums + 4 * 32;
+    static constexpr int off_flags = off_sums + 4 * 64;
+    static constexpr int off_wtx = off_flags + 4 * 32;
     static constexpr int off_wrx = off_wtx + 4 * (N + CPCS_MAX);
     static constexpr int off_tail = off_wrx + 4 * (N + TAILRX_MAX);
     static constexpr int off_lut = off_tail + 8 * 16 * TAIL_MAX;
@@ -59,6 +63,8 @@ struct wofdm_kparams {
 #ifndef WOFDM_NOISE_SCRATCH_MIN_N
 #define WOFDM_NOISE_SCRATCH_MIN_N 1024
 #endif
+// largest cp + cs the Tx window table of the kernel holds (wofdm_lds<N>::CPCS_MAX)
+static inline int wofdm_cpcs_max(int n_fft) { return n_fft >= 1024 ? 64 : 128; }
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
 static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 64 + 1 : 2 * (n_fft / 64) + 2; }
@@ -80,7 +86,8 @@ static inline int wofdm_fbuf_len(int N, int T, int spw)
 }
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
 {
-    const int fixed = 8 * N + 8 * N + 4 * 32 + 4 * (N + 128) + 4 * (N + 64) + 8 * 16 * 16 + 8 * 64;
+    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 32 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64)
+                      + 8 * 16 * 16 + 8 * 64;
     return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw));
 }
 
@@ -108,8 +115,9 @@ static inline unsigned wofdm_txfft_lds_bytes(void)
 // wofdm_kernel.hip)
 static inline unsigned wofdm_txmask_lds_bytes(int n_fft)
 {
-    const int lmax = 2 * (n_fft + 128) - 1, no = (lmax + 63) / 64, mb = 4;
-    return 8u * (unsigned)((n_fft + 128 + 2 * mb) + 64 * no + mb);
+    const int cpcs = wofdm_cpcs_max(n_fft);
+    const int lmax = 2 * (n_fft + cpcs) - 1, no = (lmax + 63) / 64, mb = 4;
+    return 8u * (unsigned)((n_fft + cpcs + 2 * mb) + 64 * no + mb);
 }
 // one translation unit per DFT length (wofdm_kernel.hip with -DWOFDM_TU_N=<N>)
 wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode, int var);

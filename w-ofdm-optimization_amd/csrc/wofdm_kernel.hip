@@ -24,6 +24,15 @@
 #include "philox.h"
 #include <type_traits>
 
+// Relaxed synchronisation (default): of the three workgroup barriers of a frame only the one in
+// front of the noise scaling is a true all-to-all (total powers).  Barrier 1 is "my predecessor
+// wave has written its symbols" and barrier 3 "the pilot wave has published the equaliser": both
+// become LDS flags carrying the loop iteration number, so that early waves run on into the next
+// phase instead of idling at the end of each one.  -DWOFDM_RELAXED_SYNC=0 restores the barriers.
+#ifndef WOFDM_RELAXED_SYNC
+#define WOFDM_RELAXED_SYNC 1
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -379,6 +388,20 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
     return x;
 }
 
+// Spin until the LDS word reaches `target` (monotonic iteration counter written by another wave
+// of the workgroup).  Bounded: a wave never hangs the GPU on a protocol error, it falls through.
+__device__ __forceinline__ void wait_flag(const volatile int *flag, int target)
+{
+    int budget = 1 << 22;
+    while (__builtin_amdgcn_readfirstlane(*flag) < target && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void post_flag(volatile int *flag, int value, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *flag = value;
+}
+
 __device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
 
 // Tx mask stage (VAR 2): a lane owns NO consecutive outputs of the 2P-1 <= 2(N+128)-1 samples of
@@ -429,6 +452,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask)
 {
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
+    // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
+    // stages have their own workgroup barriers)
+    constexpr bool RELAX = WOFDM_RELAXED_SYNC && !DUMP && VAR < 2;
     static_assert(!(TXMASK || TXFFT) || SPW == 1, "the Tx mask stage runs one symbol per wave");
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
@@ -461,6 +487,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *tw = reinterpret_cast<v2f *>(smem + L::off_tw);
     v2f *G = reinterpret_cast<v2f *>(smem + L::off_g);
     float *sums = reinterpret_cast<float *>(smem + L::off_sums);
+    volatile int *flags = reinterpret_cast<volatile int *>(smem + L::off_flags);
     float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
     float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
     v2f *tailb = reinterpret_cast<v2f *>(smem + L::off_tail);
@@ -469,6 +496,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
 
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
+    if (tid < 32) flags[tid] = 0;
+    int iter = 0;                                  // frames this workgroup has started
     fill_twiddles<N>(tw, tid, (int)blockDim.x);
     // constellation table: qammod(label) (Gray, unit average power; m:248-249)
     if (tid < (1 << K)) {
@@ -576,6 +605,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // of every stage is hoisted out of the frame loop and the kernel spills ~1500 VGPRs.
         lane = lane0;
         asm volatile("" : "+v"(lane));
+        ++iter;
+        float *sums_it = sums + 32 * (iter & 1);
         const uint64_t frame = p.frame_offset + fidx;
         const uint32_t f_lo = (uint32_t)frame, f_hi = (uint32_t)(frame >> 32);
         const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
@@ -842,7 +873,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         }
         STAMP(0);
-        __syncthreads();                                                     // ---- barrier 1
+        if constexpr (RELAX) {
+            // ---- "barrier" 1: publish "my symbols are written"; phase B waits for the
+            // predecessor wave only (its last L-1 samples and its fall tail)
+            wave_sync();
+            post_flag(&flags[wv], iter, lane);
+            if (wv > 0) wait_flag(&flags[wv - 1], iter);
+        } else {
+            __syncthreads();                                                 // ---- barrier 1
+        }
         STAMP(1);
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
@@ -874,6 +913,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int idle = 64 - nmain;
         const int ntc = (tail_total + RB - 1) / RB;
         const bool tail_in_idle = idle * W >= ntc;
+        if constexpr (RELAX) {
+            // waves that carry trailing samples of the frame read behind the last symbol
+            if (tail_in_idle && wv != W - 1 && (W - 1 - wv) * idle < ntc) wait_flag(&flags[W - 1], iter);
+        }
         is_main = lane < nmain;
         if (is_main) {
             j0 = s0 * B + lane * RB;
@@ -946,7 +989,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         ps = wave_sum(ps); pn = wave_sum(pn);
-        if (lane == 0) { sums[wv] = ps; sums[16 + wv] = pn; }
+        if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
         }
         STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
@@ -960,7 +1003,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int W = S / SPW;
         v2f *fbw = fbuf + (LT - 1) + s0 * B;
         float Ps = 0.f, Pn = 0.f;
-        for (int w2 = 0; w2 < W; ++w2) { Ps += sums[w2]; Pn += sums[16 + w2]; }
+        for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         if constexpr (RENOISE) {
             if (INJECT) {
@@ -1042,10 +1085,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
+            if constexpr (RELAX) {
+                wave_sync();
+                post_flag(&flags[16], iter, lane);
+            }
         }
         }
         STAMP(4);
-        __syncthreads();                                                     // ---- barrier 3
+        if constexpr (RELAX) {
+            if (wv != 0) wait_flag(&flags[16], iter);                        // ---- "barrier" 3
+        } else {
+            __syncthreads();                                                 // ---- barrier 3
+        }
         STAMP(5);
 
         // ------------------------------------------------------------ D: equalise, demap, count
