@@ -308,3 +308,23 @@ def test_edge_sizes(channels):
     want = O.run(_osys(st3, 2, 16, 21, True), w3t.astype(np.float64), w3r.astype(np.float64),
                  channels[:1].astype(np.complex64).astype(np.complex128), [15.0], 5, 0, 8)
     assert np.array_equal(got[..., 1], want[..., 1]) and abs(int(got[0, 0, 0, 0]) - int(want[0, 0, 0, 0])) <= 2
+
+
+@pytest.mark.parametrize("system,n_fft,k,frames", [("wtx", 256, 4, 6000), ("WOLA", 64, 2, 20000),
+                                                   ("CPW", 512, 4, 1500), ("WOLA", 1024, 6, 700)])
+def test_repeated_launches_are_bit_identical(channels, system, n_fft, k, frames):
+    """The waves of a workgroup synchronise through LDS flags and one barrier per frame; any
+    ordering bug shows up as run-to-run differences.  Same frames five times, with grids of
+    different sizes in between: the counters must not move by one bit."""
+    st = W.make_structure(system, n_fft, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.array([4.0, 12.0, 20.0], dtype=np.float32)
+    cfg = W.make_cfg(st, k, 16, 21, 2, 3, 1, seed=99)
+    with W.Plan(cfg, w_tx, w_rx, channels[60:62].astype(np.complex64), snrs) as plan:
+        first = plan.run(10, frames)
+        for _ in range(4):
+            assert np.array_equal(plan.run(10, frames), first)
+        # one ragged split (different workgroup-to-frame assignment), summed
+        a, b = plan.run(10, frames // 3), plan.run(10 + frames // 3, frames - frames // 3)
+        assert np.array_equal(a + b, first)
+    assert first[..., 0].sum() > 0
