@@ -156,6 +156,8 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         pl->nscr_wgs = grid;
     }
     kp.noise_scratch = pl->d_nscr;
+    kp.items_q = total_items / grid;
+    kp.items_r = total_items % grid;
     kp.lds_bytes = pl->base.lds_bytes;
     float2 *tm = pl->var == WOFDM_VAR_TXFFT ? pl->d_tspec : pl->d_tmask;
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm};
@@ -475,6 +477,7 @@ int wofdm_plan_dump_frame(wofdm_plan *pl, uint32_t cell, uint64_t frame, const u
         kp.dump.Xhat = f2; f2 += SN;
         kp.dump.unit_noise = f2; f2 += g.NL;
         kp.dump.gain = reinterpret_cast<float *>(f2);
+        kp.dump.sink = f2 + 1;                     // inside the 16-byte pad behind the gain
         unsigned char *b = reinterpret_cast<unsigned char *>(f2) + 16;
         kp.dump.labels_tx = b; b += SN;
         kp.dump.labels_rx = b; b += SN;

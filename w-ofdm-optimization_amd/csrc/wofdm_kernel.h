@@ -11,6 +11,8 @@ struct wofdm_kdump {          // device pointers, all may be null
     uint8_t *labels_rx;
     float   *gain;
     float2  *unit_noise;
+    float2  *sink;            // where the per-lane stage dumps of lanes without a sample go: the
+                              // instrumented kernels store unconditionally instead of branching
 };
 
 // LDS carve: fixed-size regions first (compile-time offsets), the frame buffer last.
@@ -50,6 +52,7 @@ struct wofdm_kparams {
     uint32_t inject_base_cell;   // injected arrays are indexed from this cell
     unsigned lds_bytes;
     uint64_t frames_per_cell, frame_offset;
+    uint64_t items_q, items_r;     // (cell, frame) items per workgroup: q, and one more for the first r
     uint32_t seed_lo, seed_hi;
     unsigned long long *counts;   // [cells][4]
     const uint8_t *labels;  // inject: [cells][frames][S][N]

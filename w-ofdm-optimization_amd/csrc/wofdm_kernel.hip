@@ -535,27 +535,32 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr int bps = N * ks / 128;             // Philox blocks of data bits per symbol
     static_assert(SPW * bps <= 64, "data-bit blocks of a wave must fit one pass");
 
-    // Work items (cell, frame) are walked with scalar adds/compares only: a 64-bit divide would
-    // push the (wave-uniform) loop state into VGPRs and turn every per-cell constant into a
-    // vector value.
-    const uint64_t F = p.frames_per_cell, GSTEP = gridDim.x;
-    const uint32_t cell_end = p.first_cell + p.n_cells;
-    uint32_t cell = p.first_cell;
-    uint64_t fidx = blockIdx.x;
-    int ch = 0, sn = 0, pair = 0;          // cell = (pair*n_snr + sn)*n_ch + ch
-    const int n_ch = gm[WOFDM_G_NCH], n_snr = gm[WOFDM_G_NSNR];
+    // Work items (cell, frame), cell-major: every workgroup takes one CONTIGUOUS run of them
+    // (items_q or items_q + 1 items), so that it stays on a cell for as many frames as possible --
+    // with the reference's 100 frames per cell a grid-strided walk would change cell (counter
+    // flush, channel taps, noise level) on every single frame.  One 64-bit divide per workgroup
+    // here; the loop itself steps with scalar adds and compares only.
+    const uint64_t F = p.frames_per_cell;
+    const uint64_t bq = blockIdx.x;
+    const uint64_t item0 = bq * p.items_q + (bq < p.items_r ? bq : p.items_r);
+    uint64_t n_items = p.items_q + (bq < p.items_r ? 1u : 0u);
+    const uint32_t cell_rel = (uint32_t)(item0 / F);
+    uint32_t cell = __builtin_amdgcn_readfirstlane(p.first_cell + cell_rel);
+    uint64_t fidx = item0 - (uint64_t)cell_rel * F;
     {
-        uint32_t c = 0;
-        while (c < p.first_cell) {
-            ++c;
-            if (++ch == n_ch) { ch = 0; if (++sn == n_snr) { sn = 0; ++pair; } }
-        }
+        const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fidx);
+        const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fidx >> 32));
+        fidx = ((uint64_t)fhi << 32) | flo;
     }
+    const int n_ch = gm[WOFDM_G_NCH], n_snr = gm[WOFDM_G_NSNR];
+    // cell = (pair*n_snr + sn)*n_ch + ch
+    int ch = __builtin_amdgcn_readfirstlane((int)(cell % (uint32_t)n_ch));
+    int sn = __builtin_amdgcn_readfirstlane((int)((cell / (uint32_t)n_ch) % (uint32_t)n_snr));
+    int pair = __builtin_amdgcn_readfirstlane((int)(cell / ((uint32_t)n_ch * (uint32_t)n_snr)));
     auto next_cell = [&]() {
         ++cell;
         if (++ch == n_ch) { ch = 0; if (++sn == n_snr) { sn = 0; ++pair; } }
     };
-    while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
 
     const uint32_t seed_lo = __builtin_amdgcn_readfirstlane(p.seed_lo);
     const uint32_t seed_hi = __builtin_amdgcn_readfirstlane(p.seed_hi);
@@ -583,7 +588,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-    while (cell < cell_end) {
+    for (; n_items != 0; --n_items) {
         STAMP(7);                                   // loop control, cell changes
         if (cell != cur_cell) {
             if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
@@ -931,12 +936,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         v2f nzB[RB];
         make_noise(nzB, NL);
         v2f pn2 = mk(0.f, 0.f);                          // (sum re^2, sum im^2) of the noise
+        // (instrumented builds: the per-lane dumps are unconditional stores with the address of
+        // lanes without a sample redirected to a sink word -- no divergent regions inside these
+        // register-hungry loops)
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if (r < cnt) {
-                pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
-                if (DUMP && p.dump.unit_noise) p.dump.unit_noise[j0 + r] = make_float2(nzB[r].x, nzB[r].y);
-            }
+            if (r < cnt) pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
+            if (DUMP && p.dump.unit_noise)
+                *(r < cnt ? p.dump.unit_noise + j0 + r : p.dump.sink) = make_float2(nzB[r].x, nzB[r].y);
         }
         if constexpr (!RENOISE) {
 #pragma unroll
@@ -957,10 +964,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         v2f ps2 = mk(0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if (r < cnt) {
-                ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
-                if (DUMP && p.dump.conv) p.dump.conv[j0 + r] = make_float2(acc[r].x, acc[r].y);
-            }
+            if (r < cnt) ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
+            if (DUMP && p.dump.conv)
+                *(r < cnt ? p.dump.conv + j0 + r : p.dump.sink) = make_float2(acc[r].x, acc[r].y);
         }
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
         if (!tail_in_idle && tail_total > 0 && wv == W - 1) {
@@ -1015,14 +1021,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int r = 0; r < RB; ++r) nz[r] = ns[r * 64];
             }
         }
-        if (is_main) {
+        if constexpr (DUMP) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                if (r < cnt) {
-                    const v2f y = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
-                    fbw[lane * RB + r] = y;
-                    if (DUMP && p.dump.rx) p.dump.rx[s0 * B + lane * RB + r] = make_float2(y.x, y.y);
-                }
+                const bool live = is_main && r < cnt;
+                const v2f y = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
+                if (live) fbw[lane * RB + r] = y;
+                if (p.dump.rx) *(live ? p.dump.rx + s0 * B + lane * RB + r : p.dump.sink) = make_float2(y.x, y.y);
+            }
+        } else if (is_main) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (r < cnt) fbw[lane * RB + r] = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
             }
         }
         if (DUMP && p.dump.gain && tid == 0) p.dump.gain[0] = g;
@@ -1140,8 +1150,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
 
         STAMP(6);
-        fidx += GSTEP;
-        while (fidx >= F && cell < cell_end) { fidx -= F; next_cell(); }
+        if (++fidx == F) { fidx = 0; next_cell(); }
     }
     if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
 #ifdef WOFDM_STAMP
