@@ -996,6 +996,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         ps = wave_sum(ps); pn = wave_sum(pn);
         if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
+        if constexpr (RENOISE) {
+            // the parked noise comes back HERE, after the FIR's registers have died: the HBM/L2
+            // latency of the reload runs under the wait at barrier 2 instead of opening phase C
+            if (INJECT) {
+                make_noise(nz, NL);
+            } else {
+                const v2f *ns = reinterpret_cast<const v2f *>(p.noise_scratch)
+                                + ((size_t)blockIdx.x * 16 + wv) * (RB * 64) + lane;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) nz[r] = ns[r * 64];
+            }
+        }
         }
         STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
@@ -1011,16 +1023,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
-        if constexpr (RENOISE) {
-            if (INJECT) {
-                make_noise(nz, gq[WOFDM_G_NL]);
-            } else {
-                const v2f *ns = reinterpret_cast<const v2f *>(p.noise_scratch)
-                                + ((size_t)blockIdx.x * 16 + wv) * (RB * 64) + lane;
-#pragma unroll
-                for (int r = 0; r < RB; ++r) nz[r] = ns[r * 64];
-            }
-        }
         if constexpr (DUMP) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
