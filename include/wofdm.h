@@ -143,6 +143,13 @@ int wofdm_plan_set_allocation(wofdm_plan *plan, const uint8_t *active);
  * removes the mask.  Synchronises the device. */
 int wofdm_plan_set_tx_mask(wofdm_plan *plan, const float *mask);
 
+/* Health of the plan's finished launches (call after synchronising the stream; copies one
+ * word back): WOFDM_OK, or WOFDM_E_HIP if a kernel reported that a wave gave up waiting for its
+ * workgroup -- the counters of that plan are then not to be used.  The synchronous entry points
+ * (wofdm_run, wofdm_run_injected, wofdm_plan_launch_timed) check it themselves.  Kernels report
+ * only when the library is built with -DWOFDM_CHECKED_SYNC=1 (the waits are bounded either way). */
+int wofdm_plan_status(wofdm_plan *plan);
+
 /* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
  * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
 int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);

@@ -26,7 +26,7 @@ EXPORTS = (
     "wofdm_plan_create", "wofdm_plan_destroy", "wofdm_plan_launch", "wofdm_plan_launch_timed",
     "wofdm_plan_launch_injected", "wofdm_plan_dump_frame", "wofdm_plan_info", "wofdm_run",
     "wofdm_run_injected", "wofdm_philox_kat", "wofdm_plan_set_allocation",
-    "wofdm_plan_set_tx_mask",
+    "wofdm_plan_set_tx_mask", "wofdm_plan_status",
 )
 
 
@@ -105,6 +105,7 @@ def load():
     L.wofdm_plan_info.argtypes = [vp, vp]
     L.wofdm_plan_set_allocation.argtypes = [vp, vp]
     L.wofdm_plan_set_tx_mask.argtypes = [vp, vp]
+    L.wofdm_plan_status.argtypes = [vp]
     L.wofdm_run.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp]
     L.wofdm_run_injected.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.wofdm_philox_kat.argtypes = [C.c_int, vp, vp, vp]

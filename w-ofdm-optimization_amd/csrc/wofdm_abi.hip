@@ -96,6 +96,7 @@ struct wofdm_plan {
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
+    unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
     int occ = 1, cus = 1, spw = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -156,6 +157,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         pl->nscr_wgs = grid;
     }
     kp.noise_scratch = pl->d_nscr;
+    kp.status = pl->d_status;
     kp.items_q = total_items / grid;
     kp.items_r = total_items % grid;
     kp.lds_bytes = pl->base.lds_bytes;
@@ -163,6 +165,17 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
+    return WOFDM_OK;
+}
+
+// After a synchronisation: has any kernel of this plan reported a problem?
+int check_status(wofdm_plan *pl)
+{
+    unsigned st = 0;
+    HIP_TRY(hipMemcpy(&st, pl->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st != 0)
+        return fail(WOFDM_E_HIP, "kernel status 0x%x: a wave timed out waiting for its workgroup "
+                    "(results must not be used)", st);
     return WOFDM_OK;
 }
 
@@ -264,6 +277,8 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     hipDeviceProp_t prop;
     PLAN_TRY(hipGetDeviceProperties(&prop, device));
     pl->cus = prop.multiProcessorCount;
+    PLAN_TRY(hipMalloc(&pl->d_status, sizeof(unsigned)));
+    PLAN_TRY(hipMemset(pl->d_status, 0, sizeof(unsigned)));
     if ((rc = configure(pl)) != WOFDM_OK) {
         wofdm_plan_destroy(pl);
         return rc;
@@ -291,6 +306,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_amask) (void)hipFree(pl->d_amask);
     if (pl->d_tmask) (void)hipFree(pl->d_tmask);
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
+    if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
@@ -391,6 +407,13 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
     return rc;
 }
 
+int wofdm_plan_status(wofdm_plan *pl)
+{
+    if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
+    HIP_TRY(hipSetDevice(pl->device));
+    return check_status(pl);
+}
+
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
@@ -428,7 +451,7 @@ int wofdm_plan_launch_timed(wofdm_plan *pl, uint64_t frame_offset, uint64_t fram
     HIP_TRY(hipEventRecord(pl->ev1, st));
     HIP_TRY(hipEventSynchronize(pl->ev1));
     HIP_TRY(hipEventElapsedTime(kernel_ms, pl->ev0, pl->ev1));
-    return WOFDM_OK;
+    return check_status(pl);
 }
 
 int wofdm_plan_launch_injected(wofdm_plan *pl, uint64_t frames_per_cell, const uint8_t *labels_dev,
@@ -535,6 +558,7 @@ int wofdm_run(const wofdm_cfg *cfg, int device, const float *w_tx, const float *
             rc = fail(WOFDM_E_HIP, "kernel or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
+        if ((rc = check_status(pl)) != WOFDM_OK) break;
         for (size_t i = 0; i < n; ++i) counts[i] += hc[i];
     } while (0);
     if (d) (void)hipFree(d);
@@ -573,6 +597,7 @@ int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, cons
             rc = fail(WOFDM_E_HIP, "kernel or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
+        if ((rc = check_status(pl)) != WOFDM_OK) break;
         for (size_t i = 0; i < n; ++i) counts[i] += hc[i];
     } while (0);
     if (d) (void)hipFree(d);

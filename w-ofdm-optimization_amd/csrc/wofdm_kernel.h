@@ -58,6 +58,7 @@ struct wofdm_kparams {
     const uint8_t *labels;  // inject: [cells][frames][S][N]
     const float2  *unit_noise;    // inject: [cells][frames][NL]
     float2 *noise_scratch;        // generate, N >= WOFDM_NOISE_SCRATCH_MIN_N: [grid][16][RB][64]
+    unsigned *status;             // device word, bit 0 set if a wave gave up waiting on a flag
     wofdm_kdump dump;
 };
 

@@ -32,6 +32,13 @@
 #ifndef WOFDM_RELAXED_SYNC
 #define WOFDM_RELAXED_SYNC 1
 #endif
+// The flag waits spin a bounded number of times, so a protocol error can never hang the GPU.  With
+// -DWOFDM_CHECKED_SYNC=1 a wave that runs out of budget also marks the plan's status word
+// (wofdm_plan_status); measured cost of carrying that mark through the frame loop: 0.9 % at C2,
+// so release builds leave it out.
+#ifndef WOFDM_CHECKED_SYNC
+#define WOFDM_CHECKED_SYNC 0
+#endif
 
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
@@ -390,10 +397,18 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 
 // Spin until the LDS word reaches `target` (monotonic iteration counter written by another wave
 // of the workgroup).  Bounded: a wave never hangs the GPU on a protocol error, it falls through.
-__device__ __forceinline__ void wait_flag(const volatile int *flag, int target)
+// A wave that gives up leaves a mark in LDS (gave_up), turned into bit 0 of the plan's status word
+// when the workgroup retires -- the only trace of this in the frame loop is the loop's own counter.
+__device__ __forceinline__ void wait_flag(const volatile int *flag, int target, volatile int *gave_up)
 {
     int budget = 1 << 22;
-    while (__builtin_amdgcn_readfirstlane(*flag) < target && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    while (__builtin_amdgcn_readfirstlane(*flag) < target) {
+        if (__builtin_expect(--budget == 0, 0)) {
+            if (WOFDM_CHECKED_SYNC) *gave_up = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void post_flag(volatile int *flag, int value, int lane)
@@ -883,7 +898,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // predecessor wave only (its last L-1 samples and its fall tail)
             wave_sync();
             post_flag(&flags[wv], iter, lane);
-            if (wv > 0) wait_flag(&flags[wv - 1], iter);
+            if (wv > 0) wait_flag(&flags[wv - 1], iter, &flags[20]);
         } else {
             __syncthreads();                                                 // ---- barrier 1
         }
@@ -920,7 +935,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const bool tail_in_idle = idle * W >= ntc;
         if constexpr (RELAX) {
             // waves that carry trailing samples of the frame read behind the last symbol
-            if (tail_in_idle && wv != W - 1 && (W - 1 - wv) * idle < ntc) wait_flag(&flags[W - 1], iter);
+            if (tail_in_idle && wv != W - 1 && (W - 1 - wv) * idle < ntc) wait_flag(&flags[W - 1], iter, &flags[20]);
         }
         is_main = lane < nmain;
         if (is_main) {
@@ -1105,7 +1120,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         STAMP(4);
         if constexpr (RELAX) {
-            if (wv != 0) wait_flag(&flags[16], iter);                        // ---- "barrier" 3
+            if (wv != 0) wait_flag(&flags[16], iter, &flags[20]);                        // ---- "barrier" 3
         } else {
             __syncthreads();                                                 // ---- barrier 3
         }
@@ -1155,6 +1170,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (++fidx == F) { fidx = 0; next_cell(); }
     }
     if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
+    if constexpr (RELAX && WOFDM_CHECKED_SYNC) {
+        __syncthreads();
+        if (tid == 0 && flags[20] != 0) atomicOr(p.status, 1u);   // host: results not to be used
+    }
 #ifdef WOFDM_STAMP
     if (lane0 == 0) {
         unsigned long long *dst = p.counts + 4 * (size_t)(p.first_cell + p.n_cells)

@@ -146,7 +146,13 @@ class Plan:
         counts = self.new_counts()
         self.launch(frame_offset, frames_per_cell, counts)
         torch.cuda.synchronize(self.device)
+        self.status()
         return counts.cpu().numpy().view(np.uint64)
+
+    def status(self):
+        """Raise if a finished kernel of this plan reported a problem (``wofdm_plan_status``);
+        call after synchronising."""
+        _lib.check(self.lib.wofdm_plan_status(self._h_plan))
 
     def dump_frame(self, cell, frame, labels=None, unit_noise=None):
         """Run one frame and return (counts[4], stages dict) -- parity instrumentation."""
