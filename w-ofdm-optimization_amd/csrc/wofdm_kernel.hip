@@ -1,13 +1,14 @@
 // wofdm_kernel.hip -- the fused w-OFDM frame kernel for gfx950 (MI355X, CDNA4).
 //
-// One workgroup simulates one frame at a time (persistent over a strided list of
-// (cell, frame) work items); one 64-lane wavefront owns one OFDM symbol of the frame:
+// One workgroup simulates one frame at a time (persistent over a contiguous run of the
+// cell-major (cell, frame) work items); one 64-lane wavefront owns one or two OFDM symbols of
+// the frame:
 //
 //   A  Philox bits -> Gray QAM (registers) -> N-point Stockham IFFT through the wave's own
 //      slice of the LDS frame buffer -> CP/CS copy x Tx window written straight from the
 //      last butterfly stage; the beta-sample fall tail goes to a side buffer
 //      (matlab/main_BER_calculation.m:246-252, 358-376, 419-439)
-//   -- barrier 1 --
+//   -- "barrier" 1: LDS flag of the predecessor wave --
 //   B  add the previous symbol's fall tail onto the own rise tail (overlap-add, m:253-259),
 //      21-tap complex FIR over the serialised frame from LDS (conv, m:260), Philox/Box-Muller
 //      unit noise for the same samples, per-wave partial signal/noise powers (add_wgn, m:277-294)
@@ -15,11 +16,14 @@
 //   C  r = c + g n back into the own slice (truncate + reshape, m:261-263), Rx window / fold /
 //      circular shift fused into the first FFT stage's loads (m:297-355), Stockham FFT, pilot
 //      wave publishes X0/Y0 (m:266)
-//   -- barrier 3 --
+//   -- "barrier" 3: LDS flag of the pilot wave --
 //   D  one-tap equalise, hard demap, bit/symbol error popcount in registers (m:267-272)
 //
-// No HBM traffic inside the loop in generate mode: constants come in once per cell, four
-// 64-bit counters go out once per cell.  fp32 VALU + LDS bound; no MFMA.
+// No HBM traffic inside the loop in generate mode (N = 1024 parks its unit noise in an L2-resident
+// scratch row): constants come in once per cell, four 64-bit counters go out once per cell.
+// fp32 VALU + LDS bound; no MFMA.  Template variants add the subcarrier allocation and the
+// per-symbol spectral Tx mask of main_channel_mask.m (VAR), injected randomness (INJECT) and
+// stage dumps (DUMP).
 #include "wofdm_kernel.h"
 #include "philox.h"
 #include <type_traits>
