@@ -28,7 +28,7 @@ def _cases(n_cases=120, seed=20240607):
             st = W.make_structure(system, n_fft, cp, btx, brx)
         except (AssertionError, ValueError):
             continue
-        if st.prefix_rm < 0 or st.cp + st.cs > 128 or st.stride - n_fft > 64:
+        if st.prefix_rm < 0 or st.cp + st.cs > (64 if n_fft >= 1024 else 128) or st.stride - n_fft > 64:
             continue
         opts = int(rs.choice([0, 0, 1, 2]))               # 0 plain, 1 allocation, 2 allocation + mask
         if opts == 2 and n_fft > 512:
