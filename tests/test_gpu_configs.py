@@ -1,6 +1,8 @@
 """BASELINE.json configs as parity cases.  bench.py measures C2; the
 others are checked here: against the oracle at sizes it finishes in seconds, and through
 size-independent properties at full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -182,3 +184,54 @@ def test_matlab_script_mirror_end_to_end(channels, tmp_path):
     ber = want[..., 0].sum(axis=2) / want[..., 1].sum(axis=2)
     assert np.abs(a - ber[0]).max() < 2e-5 and np.abs(b - ber[1]).max() < 2e-5
     assert (tmp_path / "ber_results" / "optimized_ber_CPwrx_14CP.mat").exists()
+
+
+def test_reference_workflow_windows_then_ber_then_mask(channels, tmp_path):
+    """The reference's scripts in sequence, every hand-over through its own file formats:
+    window_optimization.m (window_design, MATLAB flavour) -> optimal_win_*.mat ->
+    main_BER_calculation.m (driver, GPU) -> ber_results/*.mat, and main_channel_mask.m
+    (channel_mask, GPU) on the same window files; plus the Python route
+    optimization_fun -> <sys>_<cp>.npy -> simulation_fun -> ser/*.npy."""
+    from scipy.io import loadmat, savemat
+    D, WD, CM = W.driver, W.window_design, W.channel_mask
+    settings = {k: dict(v) for k, v in D.DEFAULT_SETTINGS.items()}
+    snr = np.array([0.0, 15.0, 30.0])
+    settings["generalSettings"].update(numberSubcarriers=64, cyclicPrefix=np.array([12, 16]), ensemble=40,
+                                       snrValues=snr)
+    D.save_settings(str(tmp_path / "settingsData.mat"), settings)
+    (tmp_path / "channels").mkdir()
+    savemat(str(tmp_path / "channels" / "vehA200channel2.mat"), {"vehA200channel2": channels[:4]})
+    files = WD.run_window_optimization(channels[:4], settings, str(tmp_path / "optimized_windows"),
+                                       systems=["wtx", "WOLA"])
+    assert sorted(os.path.basename(f) for f in files) == [
+        "optimal_win_WOLA_VehA200_12CP.mat", "optimal_win_WOLA_VehA200_16CP.mat",
+        "optimal_win_wtx_VehA200_12CP.mat", "optimal_win_wtx_VehA200_16CP.mat"]
+    out = D.run_ber_calculation(str(tmp_path / "settingsData.mat"), str(tmp_path / "optimized_windows"),
+                                str(tmp_path / "channels" / "vehA200channel2.mat"),
+                                str(tmp_path / "ber_results"), seed=3, log=None)
+    assert len(out) == 4
+    m = loadmat(str(tmp_path / "ber_results" / "optimized_ber_WOLA_16CP.mat"))
+    assert {"berSNRStep1A", "berSNRStep2A", "berSNRStep3A", "berSNRStep1B", "berSNRStep2B",
+            "berSNRStep3B"} <= set(m)
+    rc = loadmat(str(tmp_path / "ber_results" / "rc_ber_wtx_12CP.mat"))["berRCSNR"].ravel()
+    opt = loadmat(str(tmp_path / "ber_results" / "optimized_ber_wtx_12CP.mat"))["berSNR"].ravel()
+    assert rc.shape == opt.shape == (3,) and rc[0] > rc[2] and opt[0] > opt[2]
+    # CP = 12 < channel length: at 30 dB the interference floor dominates and the optimised Tx
+    # window (less ICI+ISI by construction) must not be worse than the raised cosine
+    assert opt[2] <= rc[2] * 1.05 + 1e-4
+    # main_channel_mask.m on one of the files
+    win = D.load_window_file(str(tmp_path / "optimized_windows" / "optimal_win_wtx_VehA200_16CP.mat"))
+    res, _ = CM.ber_for_window_file("wtx", 16, win, channels[:4], snr, num_subcar=64, ensemble=40,
+                                    tail_tx=8, tail_rx=0, seed=5)
+    assert set(res) == {"berSNR", "berMaskedSNR", "berRCSNR", "berMaskedRCSNR"}
+    paths = CM.save_results(str(tmp_path / "ber_results" / "simulation_with_channel_mask"), "wtx", 16, res)
+    assert len(paths) == 4 and all(os.path.exists(p) for p in paths)
+    assert res["berSNR"][0] > res["berSNR"][2] and res["berMaskedSNR"][0] > res["berMaskedSNR"][2]
+    # the Python route
+    cpath = tmp_path / "vehicularA.npy"
+    np.save(cpath, channels[:4].T)
+    x, _ = WD.optimization_fun(("CPwtx", 64, 16, str(cpath), str(tmp_path / "pywin")))
+    ser = W.simulation_fun(("CPwtx", 64, 16, 8, 0, str(cpath), str(tmp_path / "pywin"), 20, snr, 16,
+                            str(tmp_path / "pysim")))
+    assert os.path.exists(tmp_path / "pysim" / "ser" / "opt_CPwtx_16.npy")
+    assert os.path.exists(tmp_path / "pysim" / "ser" / "rc_CPwtx_16.npy")
