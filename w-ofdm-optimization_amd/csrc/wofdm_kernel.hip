@@ -44,6 +44,12 @@
 #define WOFDM_CHECKED_SYNC 0
 #endif
 
+// N = 512 / 1024: FFT as 8.8.8 / 16.4.16 with the outer stages in registers (fft_big); 0 = the
+// radix-4/2 ladder through LDS used for the small sizes
+#ifndef WOFDM_FFT_BIG_RADIX
+#define WOFDM_FFT_BIG_RADIX 1
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -266,11 +272,154 @@ __device__ __forceinline__ void fft_last(v2f (&v)[SPW][geo<N>::BPL][4], const v2
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------------------------
+// N = 512 / 1024: three Stockham stages  R . R2 . R  with R = 8 / 16 points held by one lane
+// (N = 8.8.8 = 16.4.16), i.e. two LDS round trips instead of four.  A lane owns elements
+// lane + 64 t, t = q + BPL r -- exactly the inputs of butterfly `lane` of a first stage of radix
+// R = 4 BPL (Ns = 1) and the outputs of butterfly `lane` of a last stage of radix R (Ns = 64),
+// so natural order in and out survives.  The in-register R-point DFT is a radix-4 pass over r,
+// constant twiddles, and a radix-4 (radix-2) pass over q.
+//
+// Twiddle table (fill_twiddles):  N = 1024: [0,48) stage 2 exp(-2 pi i r k/64) at [3k + r-1];
+// [48,1008) stage 3 exp(-2 pi i t j/1024) at [48 + 15 j + t-1].  N = 512: [0,56) stage 2
+// exp(-2 pi i t k/64) at [7k + t-1]; [56,504) stage 3 exp(-2 pi i t j/512) at [56 + 7j + t-1].
+//
+// Stage 1 stores R consecutive outputs per lane (stride R v2f across lanes: every lane on the same
+// banks); the position inside each group of R is XOR-swizzled with the group number so that a
+// store instruction spreads over all banks, and stage 2 undoes it when it loads.
+template <int R> __device__ __forceinline__ int swz(int idx)
+{
+    constexpr int LG = R == 16 ? 4 : 3;
+    const int a = idx >> LG;
+    return idx ^ ((a ^ (a >> LG)) & (R - 1));
+}
+
+// x[q][r] = x_t, t = q + 4 r   ->   x[q][r] = X_u, u = r + 4 q     (16 points)
+template <int DIR> __device__ __forceinline__ void dft16(v2f (&x)[4][4])
+{
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    // exp(-2 pi i m/16) for m = q c
+    const v2f w1 = mk(c1, -s1), w2 = mk(h, -h), w3 = mk(s1, -c1), w4 = mk(0.f, -1.f), w6 = mk(-h, -h),
+              w9 = mk(-c1, s1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) radix4<DIR>(x[q]);
+    x[1][1] = twid<DIR>(x[1][1], w1); x[1][2] = twid<DIR>(x[1][2], w2); x[1][3] = twid<DIR>(x[1][3], w3);
+    x[2][1] = twid<DIR>(x[2][1], w2); x[2][2] = twid<DIR>(x[2][2], w4); x[2][3] = twid<DIR>(x[2][3], w6);
+    x[3][1] = twid<DIR>(x[3][1], w3); x[3][2] = twid<DIR>(x[3][2], w6); x[3][3] = twid<DIR>(x[3][3], w9);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v2f col[4] = {x[0][c], x[1][c], x[2][c], x[3][c]};
+        radix4<DIR>(col);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x[d][c] = col[d];
+    }
+}
+// x[q][r] = x_t, t = q + 2 r   ->   x[q][r] = X_u, u = r + 4 q     (8 points)
+template <int DIR> __device__ __forceinline__ void dft8(v2f (&x)[2][4])
+{
+    constexpr float h = 0.70710678118654752f;
+    radix4<DIR>(x[0]);
+    radix4<DIR>(x[1]);
+    x[1][1] = twid<DIR>(x[1][1], mk(h, -h));
+    x[1][2] = twid<DIR>(x[1][2], mk(0.f, -1.f));
+    x[1][3] = twid<DIR>(x[1][3], mk(-h, -h));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const v2f a = x[0][c], b = x[1][c];
+        x[0][c] = a + b;
+        x[1][c] = a - b;
+    }
+}
+template <int N, int DIR> __device__ __forceinline__ void dft_lane(v2f (&x)[geo<N>::BPL][4])
+{
+    if constexpr (N == 1024) dft16<DIR>(x);
+    else dft8<DIR>(x);
+}
+
+template <int N, int DIR>
+__device__ __forceinline__ void fft_big(v2f (&v)[1][geo<N>::BPL][4], v2f *fb, const v2f *tw, int lane)
+{
+    static_assert(N == 512 || N == 1024, "fft_big is the 8.8.8 / 16.4.16 scheme");
+    constexpr int BPL = geo<N>::BPL, R = 4 * BPL;             // 2, 8  or  4, 16
+    constexpr int T2 = N == 1024 ? 48 : 56;                    // start of the stage-3 twiddles
+    // ---- stage 1: radix R, Ns = 1, from registers; out[R lane + u]
+    dft_lane<N, DIR>(v[0]);
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fb[swz<R>(R * lane + r + 4 * q)] = v[0][q][r];
+    wave_sync();
+    if constexpr (N == 1024) {
+        // ---- stage 2: radix 4, Ns = 16: butterflies j = lane + 64 q
+        v2f u4[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q, k = j & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u4[q][r] = fb[swz<16>(j + 256 * r)];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) u4[q][r] = twid<DIR>(u4[q][r], tw[3 * k + r - 1]);
+            radix4<DIR>(u4[q]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q, k = j & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[((j - k) << 2) + k + 16 * r] = u4[q][r];
+        }
+    } else {
+        // ---- stage 2: radix 8, Ns = 8: butterfly j = lane
+        v2f u8[2][4];
+        const int k = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = q + 2 * r;
+                u8[q][r] = fb[swz<8>(lane + 64 * t)];
+                if (t > 0) u8[q][r] = twid<DIR>(u8[q][r], tw[7 * k + t - 1]);
+            }
+        dft8<DIR>(u8);
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[((lane - k) << 3) + k + 8 * (r + 4 * q)] = u8[q][r];
+    }
+    wave_sync();
+    // ---- stage 3: radix R, Ns = 64, to registers: in[lane + 64 t], twiddle^(t lane), out lane + 64 u
+    v2f x[BPL][4];
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = q + BPL * r;
+            x[q][r] = fb[lane + 64 * t];
+            if (t > 0) x[q][r] = twid<DIR>(x[q][r], tw[T2 + (R - 1) * lane + t - 1]);
+        }
+    dft_lane<N, DIR>(x);
+    // x[q'][r'] = X_u with u = r' + 4 q';  the lane owns u = q + BPL r
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = q + BPL * r;
+            v[0][q][r] = x[u >> 2][u & 3];
+        }
+    wave_sync();
+}
+
 // registers -> (LDS stages) -> registers, natural order in and out, SPW symbols at once
 template <int N, int DIR, int SPW>
 __device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, const v2f *tw,
                                          int lane)
 {
+    if constexpr ((N == 512 || N == 1024) && WOFDM_FFT_BIG_RADIX) {
+        static_assert(SPW == 1, "one symbol per wave at N >= 512");
+        fft_big<N, DIR>(v, fb, tw, lane);
+        return;
+    }
     fft_first<N, DIR, SPW>(v, fb, sb, lane);
     if constexpr (N == 64) {
         fft_mid4<N, 4, DIR, SPW>(fb, sb, tw, lane);
@@ -296,6 +445,24 @@ __device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb,
 // Fill the per-stage twiddle tables (once per workgroup).
 template <int N> __device__ __forceinline__ void fill_twiddles(v2f *tw, int tid, int nthreads)
 {
+    if constexpr ((N == 512 || N == 1024) && WOFDM_FFT_BIG_RADIX) {
+        // tables of fft_big
+        constexpr int R = N / 64, T2 = N == 1024 ? 48 : 56;
+        for (int i = tid; i < T2 + (R - 1) * 64; i += nthreads) {
+            float num, den;
+            if (i < T2) {
+                const int per = N == 1024 ? 3 : 7;
+                num = (float)((i / per) * (1 + i % per)); den = 64.0f;                   // r k / 64
+            } else {
+                const int e = i - T2;
+                num = (float)((e / (R - 1)) * (1 + e % (R - 1))); den = (float)N;        // t j / N
+            }
+            float sv, cv;
+            sincospif(-2.0f * num / den, &sv, &cv);
+            tw[i] = mk(cv, sv);
+        }
+        return;
+    }
     int off = 0, ns = 4;
     while (ns <= N / 4) {
         const bool r2 = (N == 128 && ns == 4) || (N == 512 && ns == 16);
@@ -723,6 +890,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                     }
                     if constexpr (ALLOC) lab[u][q] |= am;
+                    // opaque at the large sizes: otherwise the unpacked labels themselves stay alive
+                    // (and spill) all the way to the pilot estimate and the demapper instead of
+                    // this one word
+                    if constexpr (N >= 512) asm volatile("" : "+v"(lab[u][q]));
                 }
             }
         }
