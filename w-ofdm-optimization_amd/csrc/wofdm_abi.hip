@@ -113,7 +113,10 @@ int configure(wofdm_plan *pl)
     const int var = pl->has_mask ? (fft_ok ? WOFDM_VAR_TXFFT : WOFDM_VAR_TXMASK)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
-    const int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B);
+    const char *cap = std::getenv("WOFDM_SPW_CAP");          // developer switch: 1, 2 or 4
+    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, var == WOFDM_VAR_PLAIN);
+    if (cap && cap[0] >= '1' && cap[0] <= '4' && spw > cap[0] - '0')
+        spw = (cap[0] == '1') ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
                          + (var == WOFDM_VAR_TXFFT ? wofdm_txfft_lds_bytes() : 0u);

@@ -410,6 +410,44 @@ __device__ __forceinline__ void fft_big(v2f (&v)[1][geo<N>::BPL][4], v2f *fb, co
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------------------------
+// N = 256, four symbols per wave ("quarter-wave" layout): 16 lanes own one symbol, lane l of the
+// quarter holds elements l + 16 t, t = q + 4 r.  256 = 16.16: both stages are in-register 16-point
+// DFTs with ONE LDS round trip between them.  Twiddles exp(-2 pi i t l/256) at tw[15 l + t-1].
+template <int DIR>
+__device__ __forceinline__ void fft_qw(v2f (&v)[1][4][4], v2f *sc, const v2f *tw, int ll)
+{
+    dft16<DIR>(v[0]);                                   // X_u at [q'][r'], u = r' + 4 q'
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[16 * ll + ((r + 4 * q) ^ ll)] = v[0][q][r];
+    wave_sync();
+    v2f x[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = q + 4 * r;
+            x[q][r] = sc[16 * t + (ll ^ t)];            // in[ll + 16 t], un-swizzled
+            if (t > 0) x[q][r] = twid<DIR>(x[q][r], tw[15 * ll + t - 1]);
+        }
+    dft16<DIR>(x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[0][q][r] = x[r][q];   // the lane owns u = q + 4 r
+    wave_sync();
+}
+__device__ __forceinline__ void fill_twiddles_qw(v2f *tw, int tid, int nthreads)
+{
+    for (int i = tid; i < 240; i += nthreads) {
+        float sv, cv;
+        sincospif(-2.0f * (float)((i / 15) * (1 + i % 15)) / 256.0f, &sv, &cv);
+        tw[i] = mk(cv, sv);
+    }
+}
+
 // registers -> (LDS stages) -> registers, natural order in and out, SPW symbols at once
 template <int N, int DIR, int SPW>
 __device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, const v2f *tw,
@@ -611,7 +649,7 @@ struct maskfft_geo {
 // the count is even and every lane starts on an even sample, so its unit noise is exactly
 // RB/2 Philox blocks (2.5 per symbol instead of 3).
 template <int N, int SPW> struct fir_geo {
-    static constexpr int RB = SPW == 1 ? N / 64 + 1 : 2 * (N / 64) + 2;
+    static constexpr int RB = SPW == 1 ? N / 64 + 1 : SPW * (N / 64) + 2;
     static constexpr bool EVEN = (SPW % 2 == 0) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
     static constexpr int CH = RB <= 6 ? RB : (RB % 5 == 0 ? 5 : 6);
@@ -631,7 +669,7 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int SPW, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__(1024 / SPW, WOFDM_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(1024 / SPW, SPW == 4 ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
@@ -645,6 +683,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
     constexpr bool FULL = geo<N>::FULL;
+    // SPW = 4: quarter-wave layout (fft_qw): 16 lanes per symbol, 16 subcarriers per lane, 4-wave
+    // workgroups, three of them per CU at up to 168 VGPRs
+    constexpr bool QW = SPW == 4;
+    static_assert(!QW || (N == 256 && VAR == 0), "the quarter-wave layout is built for N = 256, plain variant");
+    constexpr int VS = QW ? 1 : SPW, VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
     constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
     // Large DFTs would keep RB = N/64+1 noise samples AND FIR outputs per lane alive across
@@ -684,7 +727,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     if (tid < 32) flags[tid] = 0;
     int iter = 0;                                  // frames this workgroup has started
-    fill_twiddles<N>(tw, tid, (int)blockDim.x);
+    if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
+    else fill_twiddles<N>(tw, tid, (int)blockDim.x);
     // constellation table: qammod(label) (Gray, unit average power; m:248-249)
     if (tid < (1 << K)) {
         constexpr int hb = K >> 1, mm = (1 << hb) - 1;
@@ -803,8 +847,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
         ++nfr;
 
-        v2f v[SPW][BPL][4];
-        uint32_t lab[SPW][BPL];
+        v2f v[VS][VB][4];
+        uint32_t lab[VS][VB];
+        // element ownership: symbol of register slot u, subcarrier of (q, r)
+        const int usq = QW ? (lane >> 4) : 0, llq = lane & 15;
+        auto sym_of = [&](int u) { return QW ? s0 + usq : s0 + u; };
+        auto sub_of = [&](int q, int r) { return QW ? llq + 16 * (q + 4 * r) : lane + 64 * q + r * NQ; };
+        auto owns = [&](int q) { return QW || FULL || lane + 64 * q < NQ; };
         v2f acc[RB], nz[RB];
         int j0 = 0, cnt = 0;
         bool is_main;
@@ -856,24 +905,27 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             wave_sync();
         }
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            const int s = s0 + u;
-            const uint32_t *bw = reinterpret_cast<const uint32_t *>(fbw + u * B);
+        for (int u = 0; u < VS; ++u) {
+            const int s = sym_of(u);
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(fbw + (s - s0) * B);
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
+            for (int q = 0; q < VB; ++q) {
                 const int j = lane + 64 * q;
                 lab[u][q] = 0;
-                if (FULL || j < NQ) {
+                if (owns(q)) {
                     // byte r of the word: 0x80 when subcarrier j + r N/4 is NOT loaded; the flag
                     // rides in the label word (labels use 6 bits at most) down to phase D
                     uint32_t am = 0;
                     if constexpr (ALLOC) am = g_amask[j] & 0x80808080u;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int n = j + r * NQ;
+                        const int n = sub_of(q, r);
                         uint32_t Lb;
                         if (INJECT) {
                             Lb = p.labels[(inj * S + s) * N + n] & lmask;
+                        } else if constexpr (QW) {
+                            const uint32_t bit = (uint32_t)n * (uint32_t)ks;
+                            Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
                         } else {
                             // n*ks = j*ks + r*(NQ*ks); the second term is a multiple of 32 bits
                             const uint32_t bit = (uint32_t)j * (uint32_t)ks;
@@ -893,12 +945,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     // opaque at the large sizes: otherwise the unpacked labels themselves stay alive
                     // (and spill) all the way to the pilot estimate and the demapper instead of
                     // this one word
-                    if constexpr (N >= 512) asm volatile("" : "+v"(lab[u][q]));
+                    if constexpr (N >= 512 || QW) asm volatile("" : "+v"(lab[u][q]));
                 }
             }
         }
         wave_sync();
-        fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);          // v = N x[t]
+        if constexpr (QW) fft_qw<+1>(v, fbw + usq * B, tw, llq);
+        else fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);     // v = N x[t]
 
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
         // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
@@ -937,8 +990,31 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         };
-        if (rho < gq[WOFDM_G_BETA]) tx_write(std::true_type{});
-        else tx_write(std::false_type{});
+        if constexpr (QW) {
+            // the same copies with per-lane symbol geometry (the four quarters of the wave sit in
+            // four different symbols)
+            const int s = s0 + usq;
+            v2f *fb = fbw + usq * B;
+            const int Bs = (s == S - 1) ? 0x3fffffff : B;
+            const int Dt = (L::off_tail - L::off_fbuf) / 8 + s * L::TAIL_MAX - (LT - 1) - (s + 1) * B;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = llq + 16 * (q + 4 * r);
+                    const v2f x = v[0][q][r];
+                    auto put_plain = [&](int i) { fb[i] = x * wtx[i]; };
+                    auto put_tail = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = x * wtx[i]; };
+                    put_tail(t + mu);
+                    if (15 + 16 * (q + 4 * r) >= N - L::CPCS_MAX)
+                        if (t >= N - mu) put_plain(t + mu - N);
+                    if (16 * (q + 4 * r) < L::CPCS_MAX)
+                        if (t < rho) put_tail(t + mu + N);
+                }
+        } else {
+            if (rho < gq[WOFDM_G_BETA]) tx_write(std::true_type{});
+            else tx_write(std::false_type{});
+        }
 
         if constexpr (TXFFT) {
             // dft_rc_filt as fast convolution.  y[n] = sum_m g[(n - m) mod (2P-1)] x[m], n < 2P-1,
@@ -1234,15 +1310,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
         const int h2 = delta >> 1;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            const v2f *fb = fbw + u * B;
+        for (int u = 0; u < VS; ++u) {
+            const v2f *fb = fbw + (sym_of(u) - s0) * B;
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
-                if (FULL || j < NQ) {
+            for (int q = 0; q < VB; ++q) {
+                if (owns(q)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int t = j + r * NQ;
+                        const int t = sub_of(q, r);
                         const int m0 = (t + kap + h2) & (N - 1);
                         v2f z = fb[gam + m0] * wrx[m0];
                         if (m0 < delta) {
@@ -1255,26 +1330,26 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-        fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);          // v = Y[n]
+        if constexpr (QW) fft_qw<-1>(v, fbw + usq * B, tw, llq);
+        else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
 
         if (DUMP && p.dump.Y) {
 #pragma unroll
-            for (int u = 0; u < SPW; ++u)
+            for (int u = 0; u < VS; ++u)
 #pragma unroll
-                for (int q = 0; q < BPL; ++q) {
-                    const int j = lane + 64 * q;
-                    if (FULL || j < NQ)
+                for (int q = 0; q < VB; ++q) {
+                    if (owns(q))
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            p.dump.Y[(s0 + u) * N + j + r * NQ] = make_float2(v[u][q][r].x, v[u][q][r].y);
+                            p.dump.Y[sym_of(u) * N + sub_of(q, r)] = make_float2(v[u][q][r].x, v[u][q][r].y);
                 }
         }
         if (wv == 0) {
             // estimatedChannel = Y0 ./ X0 (m:266); we publish its reciprocal X0 ./ Y0
+            // (quarter-wave layout: the pilot symbol sits in lanes 0..15 of wave 0)
 #pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
-                if (FULL || j < NQ) {
+            for (int q = 0; q < VB; ++q) {
+                if (owns(q) && (!QW || usq == 0)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v2f x0 = qlut[(lab[0][q] >> (8 * r)) & lmask];
@@ -1283,7 +1358,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                         const v2f y0 = v[0][q][r];
                         const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
-                        G[j + r * NQ] = cmul_conj(x0, y0) * inv;          // X0 conj(Y0) / |Y0|^2
+                        G[sub_of(q, r)] = cmul_conj(x0, y0) * inv;        // X0 conj(Y0) / |Y0|^2
                     }
                 }
             }
@@ -1303,16 +1378,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
         // ------------------------------------------------------------ D: equalise, demap, count
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            const int s = s0 + u;
+        for (int u = 0; u < VS; ++u) {
+            const int s = sym_of(u);
             if (s > 0) {
 #pragma unroll
-                for (int q = 0; q < BPL; ++q) {
-                    const int j = lane + 64 * q;
-                    if (FULL || j < NQ) {
+                for (int q = 0; q < VB; ++q) {
+                    if (owns(q)) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int n = j + r * NQ;
+                            const int n = sub_of(q, r);
                             const v2f xh = cmul(v[u][q][r], G[n]);
                             // per-axis slicer: level index = floor((+-x*qinv + m1)/2 + 1/2), both axes
                             // in one packed fma, floor+convert in one instruction each
@@ -1397,6 +1471,9 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
     if (spw == 1) return pick_var<N, K, 1>(mode, var);
     if constexpr (N <= 256) {
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
+    }
+    if constexpr (N == 256) {
+        if (spw == 4 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
     }
     return nullptr;
 }
