@@ -997,6 +997,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             v2f *fb = fbw + usq * B;
             const int Bs = (s == S - 1) ? 0x3fffffff : B;
             const int Dt = (L::off_tail - L::off_fbuf) / 8 + s * L::TAIL_MAX - (LT - 1) - (s + 1) * B;
+            const bool body_tail = rho < gq[WOFDM_G_BETA];        // only then a body copy can reach the tail
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1005,7 +1006,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const v2f x = v[0][q][r];
                     auto put_plain = [&](int i) { fb[i] = x * wtx[i]; };
                     auto put_tail = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = x * wtx[i]; };
-                    put_tail(t + mu);
+                    if (body_tail) put_tail(t + mu);
+                    else put_plain(t + mu);
                     if (15 + 16 * (q + 4 * r) >= N - L::CPCS_MAX)
                         if (t >= N - mu) put_plain(t + mu - N);
                     if (16 * (q + 4 * r) < L::CPCS_MAX)
@@ -1205,11 +1207,19 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // (instrumented builds: the per-lane dumps are unconditional stores with the address of
         // lanes without a sample redirected to a sink word -- no divergent regions inside these
         // register-hungry loops)
+        // every lane owns exactly RB samples (e.g. four symbols of 288 samples on 64 x 18): the
+        // r < cnt predicates -- RB SGPR pairs kept alive across the FIR -- are not needed at all
+        const bool all_full = QW && !DUMP && LW == 64 * RB;
+        if (all_full) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (r < cnt) pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
-            if (DUMP && p.dump.unit_noise)
-                *(r < cnt ? p.dump.unit_noise + j0 + r : p.dump.sink) = make_float2(nzB[r].x, nzB[r].y);
+            for (int r = 0; r < RB; ++r) pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (r < cnt) pn2 = __builtin_elementwise_fma(nzB[r], nzB[r], pn2);
+                if (DUMP && p.dump.unit_noise)
+                    *(r < cnt ? p.dump.unit_noise + j0 + r : p.dump.sink) = make_float2(nzB[r].x, nzB[r].y);
+            }
         }
         if constexpr (!RENOISE) {
 #pragma unroll
@@ -1228,11 +1238,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         fir_lane<RB, fir_geo<N, SPW>::CH>(fbuf + j0, taps, acc);   // fbuf + (LT-1) + j0 - (LT-1)
 
         v2f ps2 = mk(0.f, 0.f);
+        if (all_full) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (r < cnt) ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
-            if (DUMP && p.dump.conv)
-                *(r < cnt ? p.dump.conv + j0 + r : p.dump.sink) = make_float2(acc[r].x, acc[r].y);
+            for (int r = 0; r < RB; ++r) ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (r < cnt) ps2 = __builtin_elementwise_fma(acc[r], acc[r], ps2);
+                if (DUMP && p.dump.conv)
+                    *(r < cnt ? p.dump.conv + j0 + r : p.dump.sink) = make_float2(acc[r].x, acc[r].y);
+            }
         }
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
         if (!tail_in_idle && tail_total > 0 && wv == W - 1) {
@@ -1297,6 +1312,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (live) fbw[lane * RB + r] = y;
                 if (p.dump.rx) *(live ? p.dump.rx + s0 * B + lane * RB + r : p.dump.sink) = make_float2(y.x, y.y);
             }
+        } else if (QW && SPW * B == 64 * RB) {           // every lane owns exactly RB samples
+#pragma unroll
+            for (int r = 0; r < RB; ++r) fbw[lane * RB + r] = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
         } else if (is_main) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
