@@ -114,7 +114,7 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const char *cap = std::getenv("WOFDM_SPW_CAP");          // developer switch: 1, 2 or 4
-    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, var == WOFDM_VAR_PLAIN);
+    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true);
     if (cap && cap[0] >= '1' && cap[0] <= '4' && spw > cap[0] - '0')
         spw = (cap[0] == '1') ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
@@ -325,16 +325,22 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
     int nact = N;
     if (active) {
         nact = 0;
-        std::vector<uint32_t> words((size_t)NQ, 0u);
+        // [0, NQ): word j, byte r <-> subcarrier j + r NQ; [NQ, 2 NQ): the quarter-wave order of
+        // the N = 256 kernels, word 16 q + l, byte r <-> subcarrier l + 16 (q + 4 r)
+        std::vector<uint32_t> words((size_t)2 * NQ, 0u);
         for (int n = 0; n < N; ++n) {
-            if (active[n]) ++nact;
-            else words[(size_t)(n % NQ)] |= 0x80u << (8 * (n / NQ));
+            if (active[n]) { ++nact; continue; }
+            words[(size_t)(n % NQ)] |= 0x80u << (8 * (n / NQ));
+            if (N == 256) {
+                const int l = n & 15, t = n >> 4;
+                words[(size_t)(NQ + 16 * (t & 3) + l)] |= 0x80u << (8 * (t >> 2));
+            }
         }
         if (nact == 0) return fail(WOFDM_E_INVALID, "allocation loads no subcarrier");
-        if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(pl->d_amask, words.data(), (size_t)NQ * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, (size_t)2 * NQ * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->d_amask, words.data(), (size_t)2 * NQ * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (!active && pl->d_amask) HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)NQ * sizeof(uint32_t)));
+    if (!active && pl->d_amask) HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)2 * NQ * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_NACT, &nact, sizeof(int), hipMemcpyHostToDevice));
     pl->has_alloc = active && nact < N;
     return configure(pl);
@@ -398,8 +404,8 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
         HIP_TRY(hipMemcpy(pl->d_tspec, spec.data(), (size_t)MF * sizeof(float2), hipMemcpyHostToDevice));
     }
     if (!pl->d_amask) {        // the mask kernels always read an allocation word
-        HIP_TRY(hipMalloc(&pl->d_amask, (size_t)NQ * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)NQ * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&pl->d_amask, (size_t)2 * NQ * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)2 * NQ * sizeof(uint32_t)));
     }
     const bool had = pl->has_mask;
     const char *fd = std::getenv("WOFDM_TXMASK_DIRECT");

@@ -72,7 +72,7 @@ static inline int wofdm_cpcs_max(int n_fft) { return n_fft >= 1024 ? 64 : 128; }
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
 static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 64 + 1 : spw * (n_fft / 64) + 2; }
-// symbols per wave: four at N = 256 in the plain variant (quarter-wave layout, S a multiple of 4,
+// symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
 #ifndef WOFDM_MAX_SPW

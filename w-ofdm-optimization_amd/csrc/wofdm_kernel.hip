@@ -686,7 +686,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // SPW = 4: quarter-wave layout (fft_qw): 16 lanes per symbol, 16 subcarriers per lane, 4-wave
     // workgroups, three of them per CU at up to 168 VGPRs
     constexpr bool QW = SPW == 4;
-    static_assert(!QW || (N == 256 && VAR == 0), "the quarter-wave layout is built for N = 256, plain variant");
+    static_assert(!QW || (N == 256 && VAR <= 1), "the quarter-wave layout is built for N = 256 without Tx mask");
     constexpr int VS = QW ? 1 : SPW, VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
     constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
@@ -916,7 +916,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     // byte r of the word: 0x80 when subcarrier j + r N/4 is NOT loaded; the flag
                     // rides in the label word (labels use 6 bits at most) down to phase D
                     uint32_t am = 0;
-                    if constexpr (ALLOC) am = g_amask[j] & 0x80808080u;
+                    // (second half of the table: the same flags in the quarter-wave element order)
+                    if constexpr (ALLOC) am = g_amask[QW ? NQ + 16 * q + llq : j] & 0x80808080u;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = sub_of(q, r);
@@ -1492,6 +1493,7 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
     }
     if constexpr (N == 256) {
         if (spw == 4 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 4 && var == WOFDM_VAR_ALLOC) return pick_mode<N, K, 4, WOFDM_VAR_ALLOC>(mode);
     }
     return nullptr;
 }
