@@ -860,9 +860,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // unit noise of the lane's RB samples j0.. (randn + 1j*randn, m:290)
         auto make_noise = [&](v2f (&out)[RB], int NLv) {
             if (INJECT) {
+                const float2 *src = p.unit_noise + inj * NLv + j0;
+                // two samples per 16-byte load where the lane's run starts on an even sample of an
+                // even row (always so in the two- and four-symbol layouts with even lengths)
+                if (EVEN && ((inj * NLv) & 1) == 0) {
+                    const float4 *src4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
-                    out[r] = (r < cnt) ? ldg2(p.unit_noise + inj * NLv + j0 + r) : mk(0.f, 0.f);
+                    for (int r = 0; r + 1 < RB; r += 2) {
+                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (r + 1 < cnt) t = src4[r >> 1];
+                        else if (r < cnt) { const float2 a = src[r]; t.x = a.x; t.y = a.y; }
+                        out[r] = mk(t.x, t.y);
+                        out[r + 1] = mk(t.z, t.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) out[r] = (r < cnt) ? ldg2(src + r) : mk(0.f, 0.f);
+                }
             } else {
                 // (lanes without outputs compute unused values: every later use is under r < cnt)
                 v2f cand[2 * NBK];
