@@ -70,7 +70,7 @@ class Dump(C.Structure):
 def build(verbose=False):
     """Compile libwofdm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j6"], check=True, stdout=out)
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=True, stdout=out)
     return LIB_PATH
 
 

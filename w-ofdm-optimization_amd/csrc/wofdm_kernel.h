@@ -129,21 +129,40 @@ static inline unsigned wofdm_txmask_lds_bytes(int n_fft)
     const int lmax = 2 * (n_fft + cpcs) - 1, no = (lmax + 63) / 64, mb = 4;
     return 8u * (unsigned)((n_fft + cpcs + 2 * mb) + 64 * no + mb);
 }
-// one translation unit per DFT length (wofdm_kernel.hip with -DWOFDM_TU_N=<N>)
-wofdm_kernel_fn wofdm_select_kernel_n64(int bits_per_sc, int spw, int mode, int var);
-wofdm_kernel_fn wofdm_select_kernel_n128(int bits_per_sc, int spw, int mode, int var);
-wofdm_kernel_fn wofdm_select_kernel_n256(int bits_per_sc, int spw, int mode, int var);
-wofdm_kernel_fn wofdm_select_kernel_n512(int bits_per_sc, int spw, int mode, int var);
-wofdm_kernel_fn wofdm_select_kernel_n1024(int bits_per_sc, int spw, int mode, int var);
+// one translation unit per (DFT length, bits per subcarrier): wofdm_kernel.hip with
+// -DWOFDM_TU_N=<N> -DWOFDM_TU_K=<k>
+wofdm_kernel_fn wofdm_select_kernel_n64_k2(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n64_k4(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n64_k6(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n128_k2(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n128_k4(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n128_k6(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n256_k2(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n256_k4(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n256_k6(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n512_k2(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n512_k4(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n512_k6(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n1024_k2(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n1024_k4(int spw, int mode, int var);
+wofdm_kernel_fn wofdm_select_kernel_n1024_k6(int spw, int mode, int var);
 static inline wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, int spw, int mode, int var)
 {
-    switch (n_fft) {
-    case 64: return wofdm_select_kernel_n64(bits_per_sc, spw, mode, var);
-    case 128: return wofdm_select_kernel_n128(bits_per_sc, spw, mode, var);
-    case 256: return wofdm_select_kernel_n256(bits_per_sc, spw, mode, var);
-    case 512: return wofdm_select_kernel_n512(bits_per_sc, spw, mode, var);
-    case 1024: return wofdm_select_kernel_n1024(bits_per_sc, spw, mode, var);
-    }
+    if (n_fft == 64 && bits_per_sc == 2) return wofdm_select_kernel_n64_k2(spw, mode, var);
+    if (n_fft == 64 && bits_per_sc == 4) return wofdm_select_kernel_n64_k4(spw, mode, var);
+    if (n_fft == 64 && bits_per_sc == 6) return wofdm_select_kernel_n64_k6(spw, mode, var);
+    if (n_fft == 128 && bits_per_sc == 2) return wofdm_select_kernel_n128_k2(spw, mode, var);
+    if (n_fft == 128 && bits_per_sc == 4) return wofdm_select_kernel_n128_k4(spw, mode, var);
+    if (n_fft == 128 && bits_per_sc == 6) return wofdm_select_kernel_n128_k6(spw, mode, var);
+    if (n_fft == 256 && bits_per_sc == 2) return wofdm_select_kernel_n256_k2(spw, mode, var);
+    if (n_fft == 256 && bits_per_sc == 4) return wofdm_select_kernel_n256_k4(spw, mode, var);
+    if (n_fft == 256 && bits_per_sc == 6) return wofdm_select_kernel_n256_k6(spw, mode, var);
+    if (n_fft == 512 && bits_per_sc == 2) return wofdm_select_kernel_n512_k2(spw, mode, var);
+    if (n_fft == 512 && bits_per_sc == 4) return wofdm_select_kernel_n512_k4(spw, mode, var);
+    if (n_fft == 512 && bits_per_sc == 6) return wofdm_select_kernel_n512_k6(spw, mode, var);
+    if (n_fft == 1024 && bits_per_sc == 2) return wofdm_select_kernel_n1024_k2(spw, mode, var);
+    if (n_fft == 1024 && bits_per_sc == 4) return wofdm_select_kernel_n1024_k4(spw, mode, var);
+    if (n_fft == 1024 && bits_per_sc == 6) return wofdm_select_kernel_n1024_k6(spw, mode, var);
     return nullptr;
 }
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);

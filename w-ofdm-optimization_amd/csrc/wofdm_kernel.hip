@@ -1514,34 +1514,27 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
 
 template <int N> wofdm_kernel_fn pick(int k, int spw, int mode, int var)
 {
-    switch (k) {
-#ifdef WOFDM_ONLY_K
-    case WOFDM_ONLY_K: return pick_spw<N, WOFDM_ONLY_K>(spw, mode, var);
-#else
-    case 2: return pick_spw<N, 2>(spw, mode, var);
-    case 4: return pick_spw<N, 4>(spw, mode, var);
-    case 6: return pick_spw<N, 6>(spw, mode, var);
-#endif
-    }
-    return nullptr;
+    // (one constellation size per translation unit, see below)
+    return k == WOFDM_TU_K ? pick_spw<N, WOFDM_TU_K>(spw, mode, var) : nullptr;
 }
 
 }  // namespace
 
-// This file is compiled once per DFT length (-DWOFDM_TU_N=<N>, see the Makefile) so that the
-// kernel family builds in parallel; wofdm_abi.hip dispatches on n_fft.
-#ifndef WOFDM_TU_N
-#error "compile with -DWOFDM_TU_N=<64|128|256|512|1024>"
+// This file is compiled once per (DFT length, bits per subcarrier) (-DWOFDM_TU_N=<N>
+// -DWOFDM_TU_K=<k>, see the Makefile) so that the kernel family builds in parallel;
+// wofdm_kernel.h dispatches on n_fft and bits_per_sc.
+#if !defined(WOFDM_TU_N) || !defined(WOFDM_TU_K)
+#error "compile with -DWOFDM_TU_N=<64|128|256|512|1024> -DWOFDM_TU_K=<2|4|6>"
 #endif
 #define WOFDM_CAT2(a, b) a##b
 #define WOFDM_CAT(a, b) WOFDM_CAT2(a, b)
 
-wofdm_kernel_fn WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N)(int bits_per_sc, int spw, int mode, int var)
+wofdm_kernel_fn WOFDM_CAT(WOFDM_CAT(WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N), _k), WOFDM_TU_K)(int spw, int mode, int var)
 {
-    return pick<WOFDM_TU_N>(bits_per_sc, spw, mode, var);
+    return pick<WOFDM_TU_N>(WOFDM_TU_K, spw, mode, var);
 }
 
-#if WOFDM_TU_N == 64
+#if WOFDM_TU_N == 64 && WOFDM_TU_K == 2
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s)
 {
     hipLaunchKernelGGL(philox_kat_kernel, dim3(1), dim3(64), 0, s, ctr_key_dev, out_dev);
