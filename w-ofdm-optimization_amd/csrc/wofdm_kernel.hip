@@ -1377,9 +1377,39 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             p.dump.Y[sym_of(u) * N + sub_of(q, r)] = make_float2(v[u][q][r].x, v[u][q][r].y);
                 }
         }
-        if (wv == 0) {
+        if (QW && wv == 0) {
+            // quarter-wave layout: the pilot symbol sits in lanes 0..15 of wave 0, and every other
+            // wave waits for its equaliser.  Those 16 lanes only hand their Y0 and packed labels
+            // over (through G itself and the pilot's now idle frame slice); all 64 lanes then
+            // form G, four subcarriers each.
+            uint32_t *plab = reinterpret_cast<uint32_t *>(fbw);
+            if (usq == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    plab[16 * q + llq] = lab[0][q];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) G[sub_of(q, r)] = v[0][q][r];
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = lane + 64 * i, t = n >> 4;            // n = l + 16 t, t = q + 4 r
+                const uint32_t Lb = (plab[16 * (t & 3) + (n & 15)] >> (8 * (t >> 2))) & 0xFFu;
+                v2f x0 = qlut[Lb & lmask];
+                if constexpr (ALLOC) {
+                    if (Lb & 0x80u) x0 = mk(0.f, 0.f);
+                }
+                const v2f y0 = G[n];
+                const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
+                G[n] = cmul_conj(x0, y0) * inv;
+            }
+            if constexpr (RELAX) {
+                wave_sync();
+                post_flag(&flags[16], iter, lane);
+            }
+        } else if (wv == 0) {
             // estimatedChannel = Y0 ./ X0 (m:266); we publish its reciprocal X0 ./ Y0
-            // (quarter-wave layout: the pilot symbol sits in lanes 0..15 of wave 0)
 #pragma unroll
             for (int q = 0; q < VB; ++q) {
                 if (owns(q) && (!QW || usq == 0)) {
