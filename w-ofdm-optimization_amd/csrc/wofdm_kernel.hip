@@ -1269,11 +1269,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // rare geometry (no idle lanes): trailing samples only feed the power sums
             for (int t = lane; t < tail_total; t += 64) {
                 const int j = S * B + t;
-                v2f c = mk(0.f, 0.f);
-                for (int l = 0; l < LT; ++l) {
-                    const v2f hh = taps[l];
-                    c = c + cmul(hh, fbuf[(LT - 1) + j - l]);
-                }
+                v2f c;
+                fir_chunk<1>(fbuf + j, taps, &c);      // all 21 window loads in flight at once
                 v2f nn;
                 if (INJECT) {
                     nn = ldg2(p.unit_noise + inj * NL + j);
