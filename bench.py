@@ -187,7 +187,8 @@ def main():
                          "flop_per_symbol": fs,
                          "note": "fp32 vector (VALU) roofline: the path has no dense contraction, so no "
                                  "MFMA; 157.3 TFLOP/s is both the fp32 VALU peak and the fp32 MFMA "
-                                 "dense peak. HBM is not the bound: generate mode moves O(KB) per launch."},
+                                 "dense peak. HBM is not the bound: generate mode moves ~10 MB per launch (counters, "
+                                 "constants, register-spill scratch), see traffic."},
             "ber": ber, "snr_db": SNR_DB.tolist(),
         }
         if not a.no_cpu_baseline and world == 1:       # CPU leg: rank 0 at N=1 only
