@@ -97,7 +97,7 @@ struct wofdm_plan {
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
-    int occ = 1, cus = 1, spw = 1;
+    int occ = 1, cus = 1, spw = 1;     // spw: layout id of the kernels in use (wofdm_spw)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -115,7 +115,7 @@ int configure(wofdm_plan *pl)
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const char *cap = std::getenv("WOFDM_SPW_CAP");          // developer switch: 1, 2 or 4
     int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true);
-    if (cap && cap[0] >= '1' && cap[0] <= '4' && spw > cap[0] - '0')
+    if (cap && cap[0] >= '1' && cap[0] <= '4' && wofdm_nsym(spw) > cap[0] - '0')
         spw = (cap[0] == '1') ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
@@ -133,7 +133,7 @@ int configure(wofdm_plan *pl)
     }
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / spw, lds));
+        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw), lds));
     if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
     const int fbuf = wofdm_fbuf_len(g.N, g.T, spw);
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
@@ -167,7 +167,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     float2 *tm = pl->var == WOFDM_VAR_TXFFT ? pl->d_tspec : pl->d_tmask;
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                            dim3(64u * (unsigned)(pl->g.S / pl->spw)), args, kp.lds_bytes, stream));
+                            dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), args, kp.lds_bytes, stream));
     return WOFDM_OK;
 }
 
@@ -426,7 +426,7 @@ int wofdm_plan_status(wofdm_plan *pl)
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
-    info[0] = pl->g.S / pl->spw;
+    info[0] = pl->g.S / wofdm_nsym(pl->spw);
     info[1] = (int32_t)pl->base.lds_bytes;
     info[2] = pl->cus * pl->occ;
     info[3] = pl->occ;

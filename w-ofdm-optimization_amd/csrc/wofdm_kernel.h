@@ -71,7 +71,12 @@ struct wofdm_kparams {
 static inline int wofdm_cpcs_max(int n_fft) { return n_fft >= 1024 ? 64 : 128; }
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
-static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 64 + 1 : spw * (n_fft / 64) + 2; }
+// (spw is the kernel's layout id: symbols per wave, or 5 = four symbols with 20 outputs per lane)
+static inline int wofdm_rb(int n_fft, int spw = 1)
+{
+    return spw == 1 ? n_fft / 64 + 1 : (spw == 5 ? 20 : spw * (n_fft / 64) + 2);
+}
+static inline int wofdm_nsym(int spw) { return spw == 5 ? 4 : spw; }
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
@@ -80,7 +85,10 @@ static inline int wofdm_rb(int n_fft, int spw = 1) { return spw == 1 ? n_fft / 6
 #endif
 static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false)
 {
-    if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0 && 4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
+    if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
+        if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
+        if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
+    }
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 

@@ -648,9 +648,11 @@ struct maskfft_geo {
 // FIR outputs per lane: one wave covers SPW symbols = SPW*B consecutive samples.  For SPW = 2
 // the count is even and every lane starts on an even sample, so its unit noise is exactly
 // RB/2 Philox blocks (2.5 per symbol instead of 3).
-template <int N, int SPW> struct fir_geo {
-    static constexpr int RB = SPW == 1 ? N / 64 + 1 : SPW * (N / 64) + 2;
-    static constexpr bool EVEN = (SPW % 2 == 0) && (RB % 2 == 0);
+// (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
+// lane, for strides of up to 320 samples)
+template <int N, int LAY> struct fir_geo {
+    static constexpr int RB = LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2);
+    static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
     static constexpr int CH = RB <= 6 ? RB : (RB % 5 == 0 ? 5 : 6);
 };
@@ -668,13 +670,14 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // bins flagged in g_amask carry data, the others transmit zero and are not counted
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
-template <int N, int K, int SPW, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__(1024 / SPW, SPW == 4 ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
+template <int N, int K, int LAY, bool INJECT, bool DUMP, int VAR>
+__global__ void __launch_bounds__(LAY >= 4 ? 256 : 1024 / LAY, LAY >= 4 ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
                     const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask)
 {
+    constexpr int SPW = LAY == 5 ? 4 : LAY;                  // symbols per wave
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -688,8 +691,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool QW = SPW == 4;
     static_assert(!QW || (N == 256 && VAR <= 1), "the quarter-wave layout is built for N = 256 without Tx mask");
     constexpr int VS = QW ? 1 : SPW, VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
-    constexpr int RB = fir_geo<N, SPW>::RB, NBK = fir_geo<N, SPW>::NBK;
-    constexpr bool EVEN = fir_geo<N, SPW>::EVEN;
+    constexpr int RB = fir_geo<N, LAY>::RB, NBK = fir_geo<N, LAY>::NBK;
+    constexpr bool EVEN = fir_geo<N, LAY>::EVEN;
     // Large DFTs would keep RB = N/64+1 noise samples AND FIR outputs per lane alive across
     // barrier 2 (68 VGPRs at N = 1024) and spill.  There the unit noise is parked in a per-workgroup
     // HBM scratch row ([wave][r][lane]: 512-byte coalesced rows, written and read back by the
@@ -1250,7 +1253,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         int ch_now = __builtin_amdgcn_readfirstlane(ch);
         asm volatile("" : "+s"(ch_now));
         const v2f *__restrict__ taps = g_h + ch_now * LT;
-        fir_lane<RB, fir_geo<N, SPW>::CH>(fbuf + j0, taps, acc);   // fbuf + (LT-1) + j0 - (LT-1)
+        fir_lane<RB, fir_geo<N, LAY>::CH>(fbuf + j0, taps, acc);   // fbuf + (LT-1) + j0 - (LT-1)
 
         v2f ps2 = mk(0.f, 0.f);
         if (all_full) {
@@ -1533,8 +1536,10 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
     }
     if constexpr (N == 256) {
-        if (spw == 4 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
-        if (spw == 4 && var == WOFDM_VAR_ALLOC) return pick_mode<N, K, 4, WOFDM_VAR_ALLOC>(mode);
+        if ((spw == 4 || spw == 5) && var <= WOFDM_VAR_ALLOC) {
+            if (spw == 4) return var ? pick_mode<N, K, 4, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
+            return var ? pick_mode<N, K, 5, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 5, WOFDM_VAR_PLAIN>(mode);
+        }
     }
     return nullptr;
 }
