@@ -1268,8 +1268,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
-        if (!tail_in_idle && tail_total > 0 && wv == W - 1) {
-            // rare geometry (no idle lanes): trailing samples only feed the power sums
+        if (!tail_in_idle && tail_total > 0 && wv == 0) {
+            // no idle lanes: the trailing samples (they only feed the power sums) go to wave 0, the
+            // wave that reaches barrier 2 first; it needs the last wave's symbols for them
+            if constexpr (RELAX) {
+                if (W > 1) wait_flag(&flags[W - 1], iter, &flags[20]);
+            }
             for (int t = lane; t < tail_total; t += 64) {
                 const int j = S * B + t;
                 v2f c;
