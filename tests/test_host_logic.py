@@ -198,3 +198,18 @@ def test_interference_closed_form_matches_reference(golden):
     st = V.make_structure("CP", 64, 16)
     p = W.interference.interf_power(st, np.ones(st.sym_len), np.ones(st.rx_win_len), [1.0])
     assert np.abs(p).max() < 1e-20
+
+
+def test_public_header_is_plain_c_and_matches_the_binding(tmp_path):
+    """include/wofdm.h must compile as C99 on its own (the drop-in boundary is a C ABI) and declare
+    exactly the entry points the ctypes binding expects the library to export."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "wofdm.h"\nint main(void) { wofdm_cfg c; (void)c; return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                    "-I", os.path.join(root, "include"), str(src)], check=True)
+    text = open(os.path.join(root, "include", "wofdm.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char \*|size_t)\s*(wofdm_[a-z_]+)\s*\(", text, flags=re.M))
+    assert declared == set(W._lib.EXPORTS), declared ^ set(W._lib.EXPORTS)
