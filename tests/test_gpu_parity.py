@@ -332,7 +332,9 @@ def test_repeated_launches_are_bit_identical(channels, system, n_fft, k, frames)
 
 SHARP = [("WOLA", 512, 32, 4, 16), ("CPwtx", 512, 20, 2, 16), ("wtx", 256, 32, 4, 16), ("CPW", 64, 16, 2, 16),
          ("WOLA", 1024, 32, 6, 16), ("wrx", 128, 20, 6, 16), ("WOLA", 512, 32, 6, 9), ("CPW", 256, 24, 4, 7),
-         ("CP", 1024, 16, 2, 16), ("CPwrx", 256, 32, 6, 16)]
+         ("CP", 1024, 16, 2, 16), ("CPwrx", 256, 32, 6, 16),
+         # strides of 293 / 291 samples: the 20-outputs-per-lane instantiation of the quarter-wave kernel
+         ("CPW", 256, 32, 4, 16), ("wrx", 256, 30, 2, 8)]
 
 
 @pytest.mark.parametrize("system,n_fft,cp,k,S", SHARP)
