@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer tool (build container): compile one (N, k) translation unit of the frame kernel to
+assembly and list, per instantiation, the VGPR spill stores that sit inside exec-masked
+(s_*_saveexec ... s_or_b64 exec) regions.  A spill STORE under a partial exec mask followed by a
+reload under a fuller one loses the lanes that were inactive ("Compiler
+hazard"); reloads inside such regions are harmless.
+
+    python tools/spill_scan.py 256 4
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+n, k = (sys.argv[1:3] + ["256", "4"])[:2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "w-ofdm-optimization_amd", "csrc", "wofdm_kernel.hip")
+out = os.path.join(tempfile.mkdtemp(), "k.s")
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize",
+                "-DWOFDM_TU_N=" + n, "-DWOFDM_TU_K=" + k, "-S", "--cuda-device-only", "-o", out, src],
+               check=True, stderr=subprocess.DEVNULL)
+lines = open(out).read().split("\n")
+starts = [(i, l.split(":")[0]) for i, l in enumerate(lines)
+          if l.startswith("_ZN12_GLOBAL__N_119wofdm_frames_kernel") and not l.startswith("\t")]
+print("layout inject dump var | spill stores | inside exec-masked regions | reloads inside")
+for st, name in starts:
+    tag = re.search(r"ILi\d+ELi\dELi(\d)ELb(\d)ELb(\d)ELi(\d)", name).groups()
+    end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    depth, n_st, inside, loads_in = 0, 0, 0, 0
+    for line in lines[st:end]:
+        t = line.strip()
+        if re.match(r"s_(and|andn2|or|xor)_saveexec", t):
+            depth += 1
+        elif re.match(r"s_or_b64 exec, exec", t) or re.match(r"s_mov_b64 exec", t):
+            depth = max(0, depth - 1)
+        if "scratch_store" in t:
+            n_st += 1
+            inside += depth > 0
+        if "scratch_load" in t and depth > 0:
+            loads_in += 1
+    print("  %s      %s      %s    %s  | %4d | %4d | %4d" % (tag + (n_st, inside, loads_in)))
