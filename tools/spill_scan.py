@@ -30,7 +30,9 @@ for st, name in starts:
     depth, n_st, inside, loads_in = 0, 0, 0, 0
     for line in lines[st:end]:
         t = line.strip()
-        if re.match(r"s_(and|andn2|or|xor)_saveexec", t):
+        # if: s_and(n2)_saveexec opens; else: s_or_saveexec + s_xor exec stays at the same depth;
+        # endif: s_or_b64 exec, exec, saved.  (A heuristic: exec arithmetic is not interpreted.)
+        if re.match(r"s_(and|andn2)_saveexec", t):
             depth += 1
         elif re.match(r"s_or_b64 exec, exec", t) or re.match(r"s_mov_b64 exec", t):
             depth = max(0, depth - 1)
