@@ -236,7 +236,9 @@ def fixture_interference(ch):
 def fixture_window_design(ch):
     """Window design (optimizers.py:25-873): the reference's Hessians (its own O(P^2 N^2) loops,
     un-jitted) and the minimisers of its own solvers, at N=32, CP=12, tails 8/10, for the mean
-    of the first 20 channel realisations."""
+    of the first 20 channel realisations.  (Re-running this reproduces the Hessians to 1e-15;
+    the WOLA/CPW minimisers of scipy's trust-constr move by ~3e-8 from run to run -- threaded
+    BLAS -- far inside the 2e-5 the test allows.)"""
     from optimization_tools.optimizers import OptimizerRx, OptimizerTx, OptimizerTxRx
     n_fft, cp = 32, 12
     h_avg = ch[:, :20].mean(axis=1)
