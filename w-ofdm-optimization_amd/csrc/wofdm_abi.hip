@@ -97,6 +97,8 @@ struct wofdm_plan {
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
+    uint4 *d_fira = nullptr;           // [n_ch][4][64] Toeplitz operands of the matrix-pipe FIR (MFMA A layout)
+    float firm_sx = 1.f, firm_sh = 1.f; // powers of two carried by the f16 samples / f16 taps there
     int occ = 1, cus = 1, spw = 1;     // spw: layout id of the kernels in use (wofdm_spw)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -114,10 +116,12 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const char *cap = std::getenv("WOFDM_SPW_CAP");          // developer switch: 1, 2 or 4
-    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true);
+    const char *fv = std::getenv("WOFDM_FIR_VALU");          // developer switch: 1 = FIR on the VALU everywhere
+    const bool firm = !(fv && fv[0] == '1');
+    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm);
     if (cap && cap[0] >= '1' && cap[0] <= '4' && wofdm_nsym(spw) > cap[0] - '0')
         spw = (cap[0] == '1') ? 1 : wofdm_spw(g.N, g.S, g.B, false);
-    const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw)
+    const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
                          + (var == WOFDM_VAR_TXFFT ? wofdm_txfft_lds_bytes() : 0u);
     if (lds > 160u * 1024u)
@@ -135,10 +139,16 @@ int configure(wofdm_plan *pl)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw), lds));
     if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
-    const int fbuf = wofdm_fbuf_len(g.N, g.T, spw);
+    const int fbuf = wofdm_fbuf_len(g.N, g.T, spw, g.S, g.B);
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
     for (int m = 0; m < 4; ++m) pl->fn[m] = fn[m];
     pl->var = var; pl->spw = spw; pl->occ = occ; pl->base.lds_bytes = lds;
+    // scale of the on-air samples inside the kernel (wofdm_kparams): 1/N of the IDFT, times the
+    // f16 centring of the matrix-pipe layouts
+    const bool fm = wofdm_is_firm(spw);
+    pl->base.tx_scale = (fm ? pl->firm_sx : 1.0f) / (float)g.N;
+    pl->base.dump_unscale_tx = fm ? 1.0f / pl->firm_sx : 1.0f;
+    pl->base.dump_unscale_rx = fm ? 1.0f / (pl->firm_sx * pl->firm_sh) : 1.0f;
     return WOFDM_OK;
 }
 
@@ -165,7 +175,11 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     kp.items_r = total_items % grid;
     kp.lds_bytes = pl->base.lds_bytes;
     float2 *tm = pl->var == WOFDM_VAR_TXFFT ? pl->d_tspec : pl->d_tmask;
-    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm};
+    kp.tx_scale = pl->base.tx_scale;
+    kp.dump_unscale_tx = pl->base.dump_unscale_tx;
+    kp.dump_unscale_rx = pl->base.dump_unscale_rx;
+    void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
+                    &pl->d_fira};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
                             dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), args, kp.lds_bytes, stream));
     return WOFDM_OK;
@@ -239,6 +253,35 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
         for (int l = 0; l < g.L; ++l)
             hp[(size_t)c * WOFDM_LT + l] = make_float2(h[2 * ((size_t)c * g.L + l)],
                                                        h[2 * ((size_t)c * g.L + l) + 1]);
+    // Matrix-pipe FIR (wofdm_kernel.hip, phase B of layouts 6 and 7): per channel the 16 x 64 block
+    // A[2i + o][2jj + c] = {hr, -hi; hi, hr}[o][c] of tap i + 24 - jj (i < 8 outputs, jj < 32 window
+    // samples), scaled by a power of two and split into f16 hi + lo, in the operand layout of
+    // v_mfma_f32_16x16x32_f16: lane (m = lane % 16, kg = lane / 16) holds columns 8 kg .. 8 kg + 7
+    // of row m of one K = 32 half.  fira[ch][2 half + part][lane] = 8 halves.
+    double hmax = 0.0, wmax = 0.0;
+    for (float v : std::vector<float>(h, h + 2 * (size_t)cfg->n_channels * g.L)) hmax = std::fmax(hmax, std::fabs((double)v));
+    for (size_t i = 0; i < n_wtx; ++i) wmax = std::fmax(wmax, std::fabs((double)w_tx[i]));
+    // taps: largest component in [512, 1024); samples: |x| <= wmax * 1.53 (largest 64-QAM point) * N
+    // before the table's 1/N, kept below 2^15
+    pl->firm_sh = hmax > 0.0 ? (float)std::exp2(9.0 - std::floor(std::log2(hmax))) : 1.0f;
+    pl->firm_sx = wmax > 0.0 ? (float)std::exp2(std::floor(std::log2(32768.0 / (wmax * 1.53)))) : 1.0f;
+    std::vector<_Float16> fira((size_t)cfg->n_channels * 4 * 64 * 8);
+    for (int c = 0; c < cfg->n_channels; ++c)
+        for (int a = 0; a < 4; ++a)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int hf = a >> 1, part = a & 1, m = lane & 15, kg = lane >> 4;
+                    const int jj = 16 * hf + 4 * kg + (e >> 1), cc = e & 1, i = m >> 1, o = m & 1;
+                    const int l = i + 24 - jj;
+                    double val = 0.0;
+                    if (l >= 0 && l < g.L) {
+                        const double hr = h[2 * ((size_t)c * g.L + l)], hi = h[2 * ((size_t)c * g.L + l) + 1];
+                        val = (o == 0 ? (cc == 0 ? hr : -hi) : (cc == 0 ? hi : hr)) * (double)pl->firm_sh;
+                    }
+                    const _Float16 vh = (_Float16)val;
+                    const _Float16 vl = (_Float16)(val - (double)vh);
+                    fira[(((size_t)c * 4 + a) * 64 + lane) * 8 + e] = part ? vl : vh;
+                }
     std::vector<float> nlin(cfg->n_snr);
     for (int i = 0; i < cfg->n_snr; ++i) nlin[i] = (float)std::pow(10.0, -0.1 * (double)snr_db[i]);
 
@@ -260,6 +303,8 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     PLAN_TRY(hipMemcpy(pl->d_wrx, w_rx, n_wrx * sizeof(float), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(pl->d_h, hp.data(), hp.size() * sizeof(float2), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(pl->d_nlin, nlin.data(), nlin.size() * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMalloc(&pl->d_fira, fira.size() * sizeof(_Float16)));
+    PLAN_TRY(hipMemcpy(pl->d_fira, fira.data(), fira.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     PLAN_TRY(hipEventCreate(&pl->ev0));
     PLAN_TRY(hipEventCreate(&pl->ev1));
 
@@ -310,6 +355,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_tmask) (void)hipFree(pl->d_tmask);
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
     if (pl->d_status) (void)hipFree(pl->d_status);
+    if (pl->d_fira) (void)hipFree(pl->d_fira);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;

@@ -59,6 +59,12 @@ struct wofdm_kparams {
     const float2  *unit_noise;    // inject: [cells][frames][NL]
     float2 *noise_scratch;        // generate, N >= WOFDM_NOISE_SCRATCH_MIN_N: [grid][16][RB][64]
     unsigned *status;             // device word, bit 0 set if a wave gave up waiting on a flag
+    // Scaling of the on-air signal inside the kernel.  The Tx window table holds w_tx * tx_scale
+    // (1/N of the IDFT, and in the matrix-pipe FIR layouts a power of two that centres the samples
+    // in the f16 range); the channel's Toeplitz operands carry their own power of two.  Everything
+    // behind the FIR is homogeneous in that scale (the noise gain is derived from the measured
+    // powers, the equaliser divides by the pilot), so only the stage dumps undo it.
+    float tx_scale, dump_unscale_tx, dump_unscale_rx;
     wofdm_kdump dump;
 };
 
@@ -72,20 +78,29 @@ static inline int wofdm_cpcs_max(int n_fft) { return n_fft >= 1024 ? 64 : 128; }
 static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // FIR outputs per lane for `spw` symbols per wave (fir_geo in wofdm_kernel.hip)
 // (spw is the kernel's layout id: symbols per wave, or 5 = four symbols with 20 outputs per lane)
+// 6 / 7 = four symbols per wave with the FIR on the matrix pipe (wofdm_firm_tiles tiles of 128
+// samples per wave, two samples per lane and tile)
+static inline bool wofdm_is_firm(int spw) { return spw == 6 || spw == 7; }
+static inline int wofdm_firm_tiles(int spw) { return spw == 7 ? 10 : 9; }
+#define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
 static inline int wofdm_rb(int n_fft, int spw = 1)
 {
+    if (wofdm_is_firm(spw)) return 2 * wofdm_firm_tiles(spw);
     return spw == 1 ? n_fft / 64 + 1 : (spw == 5 ? 20 : spw * (n_fft / 64) + 2);
 }
-static inline int wofdm_nsym(int spw) { return spw == 5 ? 4 : spw; }
+static inline int wofdm_nsym(int spw) { return (spw == 5 || wofdm_is_firm(spw)) ? 4 : spw; }
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
 #ifndef WOFDM_MAX_SPW
 #define WOFDM_MAX_SPW 4
 #endif
-static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false)
+static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool firm = true)
 {
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
+        // matrix-pipe FIR: sample pairs must not straddle a symbol (B even)
+        if (firm && B % 2 == 0 && 4 * B <= 128 * wofdm_firm_tiles(6)) return 6;
+        if (firm && B % 2 == 0 && 4 * B <= 128 * wofdm_firm_tiles(7)) return 7;
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
@@ -98,22 +113,29 @@ static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
     return n_fft >= WOFDM_NOISE_SCRATCH_MIN_N ? (size_t)16 * 64 * wofdm_rb(n_fft, spw) : 0;
 }
 
-static inline int wofdm_fbuf_len(int N, int T, int spw)
+// float2 elements of the frame buffer.  Matrix-pipe layouts: the same bytes hold two planes of
+// packed-f16 words (hi and lo halves of every sample), each `len` words long: 24 zeros, the frame,
+// and zeros up to the end of the tile that covers the trailing samples behind the last wave.
+static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
+    if (wofdm_is_firm(spw))
+        return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
-static inline unsigned wofdm_lds_bytes(int N, int T, int spw)
+static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S = 0, int B = 0)
 {
     const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 32 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64)
                       + 8 * 16 * 16 + 8 * 64;
-    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw));
+    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B));
 }
 
 // kernel registry (wofdm_kernel.hip)
 // constants travel as separate noalias arguments so that uniform reads become scalar loads:
 // w_tx[pairs][P], w_rx[pairs][N+delta], h[n_ch][WOFDM_LT] zero padded, noise_lin[n_snr]
+// fira[n_ch][4][64] (uint4): the channel's Toeplitz operands of the matrix-pipe FIR, in MFMA A layout
 typedef void (*wofdm_kernel_fn)(wofdm_kparams, const float *, const float *, const float2 *,
-                                const float *, const int *, const uint32_t *, const float2 *);
+                                const float *, const int *, const uint32_t *, const float2 *,
+                                const uint4 *);
 enum { WOFDM_MODE_GEN = 0, WOFDM_MODE_INJECT = 1, WOFDM_MODE_DUMP_GEN = 2, WOFDM_MODE_DUMP_INJECT = 3 };
 // kernel variants: every subcarrier loaded / a subcarrier allocation mask / allocation + per-symbol
 // spectral Tx mask (one symbol per wave, n_fft <= WOFDM_TXMASK_MAX_N: the mask table needs LDS)

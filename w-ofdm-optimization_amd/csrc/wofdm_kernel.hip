@@ -69,7 +69,8 @@ namespace {
         __builtin_amdgcn_sched_barrier(0);                                                     \
     } while (0)
 #else
-#define STAMP(slot) do { } while (0)
+// (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
+#define STAMP(slot) asm volatile("; wofdm_mark " #slot)
 #endif
 
 // Complex samples are 2-wide float vectors: gfx950 issues one wave64 VALU instruction per
@@ -79,6 +80,26 @@ namespace {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
+
+// Matrix-pipe FIR (layouts 6, 7): samples travel through LDS as two packed-f16 words, y = hi + lo
+// with both halves rounded to nearest: |y - hi - lo| <= 2^-24 |y|, so that three f16 MFMA terms
+// (h_hi x_hi + h_hi x_lo + h_lo x_hi, fp32 accumulation) reproduce the fp32 product to ~2^-23.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
+{
+    const h2 h = __builtin_convertvector(y, h2);                       // v_cvt_pk_f16_f32 (RNE)
+    const h2 l = __builtin_convertvector(y - __builtin_convertvector(h, v2f), h2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ v2f join_h(uint32_t hi, uint32_t lo)
+{
+    return __builtin_convertvector(__builtin_bit_cast(h2, hi), v2f)
+           + __builtin_convertvector(__builtin_bit_cast(h2, lo), v2f);
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -651,7 +672,8 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2);
+    static constexpr int RB = LAY >= 6 ? (LAY == 7 ? 20 : 18)
+                              : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
     static constexpr int CH = RB <= 6 ? RB : (RB % 5 == 0 ? 5 : 6);
@@ -675,9 +697,14 @@ __global__ void __launch_bounds__(LAY >= 4 ? 256 : 1024 / LAY, LAY >= 4 ? 3 : WO
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
-                    const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask)
+                    const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask,
+                    const uint4 *__restrict__ g_fira)
 {
-    constexpr int SPW = LAY == 5 ? 4 : LAY;                  // symbols per wave
+    constexpr int SPW = LAY >= 5 ? 4 : LAY;                  // symbols per wave
+    // layouts 6, 7: quarter-wave layout with the 21-tap FIR on the matrix pipe as a block-Toeplitz
+    // product (NT tiles of 128 samples per wave; see phase B)
+    constexpr bool FIRM = LAY >= 6;
+    constexpr int NT = LAY == 7 ? 10 : 9, PRE = WOFDM_FIRM_PRE;
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -726,6 +753,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *qlut = reinterpret_cast<v2f *>(smem + L::off_lut);
     v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
+    // Matrix-pipe layouts: the frame buffer's bytes are two planes of packed-f16 words, Hp[i] / Lp[i] =
+    // hi / lo halves (re | im << 16) of sample i - PRE, Lp = Hp + plen (plen = gm[WOFDM_G_FBUF]); the fall
+    // tails likewise (tH, tL).  Wave w's four symbol rows of B words in EACH plane double as its
+    // private scratch: 2 x 4B words = four rows of B complex floats (row()).
+    uint32_t *Hp = reinterpret_cast<uint32_t *>(smem + L::off_fbuf);
+    uint32_t *tH = reinterpret_cast<uint32_t *>(smem + L::off_tail), *tL = tH + 16 * L::TAIL_MAX;
 
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     if (tid < 32) flags[tid] = 0;
@@ -831,7 +864,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // 1/N of the IDFT (dftmtx(N)'/N, m:370) is folded into the Tx window copy
                 const int P = gm[WOFDM_G_P], delta = gm[WOFDM_G_DELTA];
                 for (int i = tid; i < P; i += blockDim.x)
-                    wtx[i] = g_wtx[(size_t)pair * P + i] * (1.0f / (float)N);
+                    wtx[i] = g_wtx[(size_t)pair * P + i] * p.tx_scale;
                 for (int i = tid; i < N + delta; i += blockDim.x)
                     wrx[i] = g_wrx[(size_t)pair * (N + delta) + i];
                 __syncthreads();
@@ -908,14 +941,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], mu = gq[WOFDM_G_MU], rho = gq[WOFDM_G_RHO];
+        const int plen = FIRM ? gq[WOFDM_G_FBUF] : 0;
         v2f *fbw = fbuf + (LT - 1) + s0 * B;       // this wave's SPW symbol slices of the frame
+        // private row of B complex floats of the wave's symbol slot u (scratch of the transforms,
+        // later the received block)
+        auto row = [&](int u) -> v2f * {
+            if constexpr (FIRM)
+                return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
+            else
+                return fbw + u * B;
+        };
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
             if (lane < SPW * bps) {
                 const int ub = lane / bps, blk = lane % bps;
                 const philox_out o = stream_block((uint32_t)((s0 + ub) * bps + blk), f_lo, f_hi,
                                                   (WOFDM_STREAM_BITS << 28) | cell, seed_lo, seed_hi);
-                uint32_t *bw = reinterpret_cast<uint32_t *>(fbw + ub * B);
+                uint32_t *bw = reinterpret_cast<uint32_t *>(row(ub));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bw[4 * blk + i] = o.w[i];
             }
@@ -924,7 +966,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const int s = sym_of(u);
-            const uint32_t *bw = reinterpret_cast<const uint32_t *>(fbw + (s - s0) * B);
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(row(s - s0));
 #pragma unroll
             for (int q = 0; q < VB; ++q) {
                 const int j = lane + 64 * q;
@@ -968,7 +1010,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-        if constexpr (QW) fft_qw<+1>(v, fbw + usq * B, tw, llq);
+        if constexpr (QW) fft_qw<+1>(v, row(usq), tw, llq);
         else fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);     // v = N x[t]
 
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
@@ -1008,7 +1050,42 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         };
-        if constexpr (QW) {
+        if constexpr (FIRM) {
+            // the same copies, every sample split into its two packed-f16 words; the fall tail goes to
+            // the tail planes, DtH / DtL words away from the row's word in plane H / L
+            const int s = s0 + usq;
+            uint32_t *hrow = Hp + PRE + s * B;
+            const int Bs = (s == S - 1) ? 0x3fffffff : B;
+            const int DtH = (L::off_tail - L::off_fbuf) / 4 + s * L::TAIL_MAX - (PRE + (s + 1) * B);
+            const int DtL = DtH + 16 * L::TAIL_MAX - plen;
+            const bool body_tail = rho < gq[WOFDM_G_BETA];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = llq + 16 * (q + 4 * r);
+                    const v2f x = v[0][q][r];
+                    auto put_plain = [&](int i) {
+                        uint32_t hi, lo;
+                        split_h(x * wtx[i], hi, lo);
+                        hrow[i] = hi;
+                        hrow[i + plen] = lo;
+                    };
+                    auto put_tail = [&](int i) {
+                        uint32_t hi, lo;
+                        split_h(x * wtx[i], hi, lo);
+                        const bool tl = i >= Bs;
+                        hrow[i + (tl ? DtH : 0)] = hi;
+                        hrow[i + plen + (tl ? DtL : 0)] = lo;
+                    };
+                    if (body_tail) put_tail(t + mu);
+                    else put_plain(t + mu);
+                    if (15 + 16 * (q + 4 * r) >= N - L::CPCS_MAX)
+                        if (t >= N - mu) put_plain(t + mu - N);
+                    if (16 * (q + 4 * r) < L::CPCS_MAX)
+                        if (t < rho) put_tail(t + mu + N);
+                }
+        } else if constexpr (QW) {
             // the same copies with per-lane symbol geometry (the four quarters of the wave sit in
             // four different symbols)
             const int s = s0 + usq;
@@ -1176,7 +1253,154 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(1);
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
+        if constexpr (FIRM) {
+        // The 21-tap complex FIR as a block-Toeplitz product on the matrix pipe.  One
+        // v_mfma_f32_16x16x32_f16 tile = 8 consecutive outputs (re and im rows interleaved: 16 rows)
+        // of 16 blocks (columns), K = 32 window samples x (re, im) in two instructions of K = 32:
+        //   y[8b + i] = sum_l h[l] x[8b + i - l]:   A[2i + o][2jj + c] = { hr, -hi ; hi, hr }[o][c] of
+        //   tap i + 24 - jj,   B[2jj + c][b] = (re, im)[c] of x[8b - 24 + jj],   jj = 0..31.
+        // Operands are f16 pairs (hi + lo, split_h): h_hi x_hi + h_hi x_lo + h_lo x_hi in fp32
+        // accumulation = 6 MFMAs per tile of 128 samples; lane (column n, row group g) receives the
+        // complex samples 8n + 2g and 8n + 2g + 1 of the tile as (re, im, re, im) -- the unit noise of
+        // exactly these two samples is one Philox block.  The A operands (per channel, built by the
+        // host in MFMA layout) come from L2; the B operands are 16-byte rows of the f16 planes.
+        GEO_PHASE();
+        const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
+        const int plen = gq[WOFDM_G_FBUF];
+        const int W = S / SPW;
+        uint32_t *Lp = Hp + plen;
+        int ch_now = __builtin_amdgcn_readfirstlane(ch);
+        asm volatile("" : "+s"(ch_now));
+        const u4 *fa = reinterpret_cast<const u4 *>(g_fira) + (size_t)ch_now * 256 + lane;
+        h8 A[4];                                   // [2 half + part]: window half 0/1, h_hi / h_lo
+#pragma unroll
+        for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(h8, fa[64 * a]);
         {
+            // overlap-add of the previous symbol's fall tail (m:253-259), in fp32, re-split
+            const int s = s0 + usq;
+            if (s > 0 && llq < beta) {
+                const int idx = PRE + s * B + llq, it = (s - 1) * L::TAIL_MAX + llq;
+                uint32_t hi, lo;
+                split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
+                Hp[idx] = hi;
+                Lp[idx] = lo;
+            }
+        }
+        wave_sync();
+        if (DUMP) {
+            __syncthreads();
+            if (p.dump.tx)
+                for (int i = tid; i < gq[WOFDM_G_T]; i += blockDim.x) {
+                    const v2f t = join_h(Hp[PRE + i], Lp[PRE + i]) * p.dump_unscale_tx;
+                    p.dump.tx[i] = make_float2(t.x, t.y);
+                }
+            __syncthreads();
+        }
+        const int jl = 8 * llq + 2 * usq;               // the lane's samples of a tile: jl, jl + 1
+        const int jw = s0 * B, LW = SPW * B;
+        const bool all_full = !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
+        const v2f zero2 = mk(0.f, 0.f);
+        v2f pn2 = zero2, ps2 = zero2;
+        auto noise_pair = [&](int j, bool v0, bool v1, v2f &n0, v2f &n1) {   // samples j (even), j + 1
+            if (INJECT) {
+                const float2 *src = p.unit_noise + inj * NL + j;
+                n0 = zero2; n1 = zero2;
+                if (v0 && v1 && ((inj * NL) & 1) == 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    n0 = mk(t.x, t.y); n1 = mk(t.z, t.w);
+                } else {
+                    if (v0) n0 = ldg2(src);
+                    if (v1) n1 = ldg2(src + 1);
+                }
+            } else {
+                const philox_out o = stream_block((uint32_t)j >> 1, f_lo, f_hi,
+                                                  (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
+                n0 = box_muller(o.w[0], o.w[1]);
+                n1 = box_muller(o.w[2], o.w[3]);
+            }
+        };
+        auto fir_tile = [&](const uint32_t *b) -> f4 {     // b = plane-H word of x[first output - 24] + 4 g
+            const h8 h0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b));
+            const h8 h1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + 16));
+            const h8 l0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen));
+            const h8 l1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen + 16));
+            f4 d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], h0, d, 0, 0, 0);      // h_lo x_hi
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], h1, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], l0, d, 0, 0, 0);      // h_hi x_lo
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], l1, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], h0, d, 0, 0, 0);      // h_hi x_hi
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], h1, d, 0, 0, 0);
+            return d;
+        };
+        // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
+        const uint32_t *bh = Hp + jw + 8 * llq + 4 * usq;
+#pragma unroll
+        for (int G = 0; G < NT; ++G) {
+            const int jr = 128 * G + jl;
+            const bool valid = all_full || jr < LW;
+            v2f n0, n1;
+            noise_pair(jw + jr, valid, valid, n0, n1);
+            const f4 d = fir_tile(bh + 128 * G);
+            const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
+            nz[2 * G] = n0; nz[2 * G + 1] = n1;
+            acc[2 * G] = c0; acc[2 * G + 1] = c1;
+            // (selects, not branches: columns behind the wave's samples may hold anything)
+            const v2f a0 = valid ? c0 : zero2, a1 = valid ? c1 : zero2;
+            const v2f m0 = valid ? n0 : zero2, m1 = valid ? n1 : zero2;
+            ps2 = __builtin_elementwise_fma(a0, a0, ps2);
+            ps2 = __builtin_elementwise_fma(a1, a1, ps2);
+            pn2 = __builtin_elementwise_fma(m0, m0, pn2);
+            pn2 = __builtin_elementwise_fma(m1, m1, pn2);
+            if (DUMP) {
+                const v2f e0 = c0 * p.dump_unscale_rx, e1 = c1 * p.dump_unscale_rx;
+                if (p.dump.conv) {
+                    float2 *dc = valid ? p.dump.conv + jw + jr : p.dump.sink;
+                    dc[0] = make_float2(e0.x, e0.y);
+                    dc[valid ? 1 : 0] = make_float2(e1.x, e1.y);
+                }
+                if (p.dump.unit_noise) {
+                    float2 *dn = valid ? p.dump.unit_noise + jw + jr : p.dump.sink;
+                    dn[0] = make_float2(n0.x, n0.y);
+                    dn[valid ? 1 : 0] = make_float2(n1.x, n1.y);
+                }
+            }
+        }
+        const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
+        if (tail_total > 0 && wv == 0) {
+            // the trailing samples of the frame (they only feed the power sums): one more tile, by
+            // wave 0, the wave that reaches barrier 2 first; it reads behind the last wave's symbols
+            if constexpr (RELAX) {
+                if (W > 1) wait_flag(&flags[W - 1], iter, &flags[20]);
+            }
+            const int jt = S * B;
+            const bool v0 = jl < tail_total, v1 = jl + 1 < tail_total;
+            v2f n0, n1;
+            noise_pair(jt + jl, v0, v1, n0, n1);
+            const f4 d = fir_tile(Hp + jt + 8 * llq + 4 * usq);
+            const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
+            const v2f a0 = v0 ? c0 : zero2, a1 = v1 ? c1 : zero2;
+            const v2f m0 = v0 ? n0 : zero2, m1 = v1 ? n1 : zero2;
+            ps2 = __builtin_elementwise_fma(a0, a0, ps2);
+            ps2 = __builtin_elementwise_fma(a1, a1, ps2);
+            pn2 = __builtin_elementwise_fma(m0, m0, pn2);
+            pn2 = __builtin_elementwise_fma(m1, m1, pn2);
+            if (DUMP) {
+                const v2f e0 = c0 * p.dump_unscale_rx, e1 = c1 * p.dump_unscale_rx;
+                if (p.dump.conv) {
+                    *(v0 ? p.dump.conv + jt + jl : p.dump.sink) = make_float2(e0.x, e0.y);
+                    *(v1 ? p.dump.conv + jt + jl + 1 : p.dump.sink) = make_float2(e1.x, e1.y);
+                }
+                if (p.dump.unit_noise) {
+                    *(v0 ? p.dump.unit_noise + jt + jl : p.dump.sink) = make_float2(n0.x, n0.y);
+                    *(v1 ? p.dump.unit_noise + jt + jl + 1 : p.dump.sink) = make_float2(n1.x, n1.y);
+                }
+            }
+        }
+        float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
+        ps = wave_sum(ps); pn = wave_sum(pn);
+        if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
+        } else {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
         const int W = S / SPW;                         // waves per workgroup
@@ -1319,11 +1543,42 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
         const int gam = gq[WOFDM_G_GAMMA], kap = gq[WOFDM_G_KAPPA];
         const int W = S / SPW;
+        const int plen = FIRM ? gq[WOFDM_G_FBUF] : 0;
         v2f *fbw = fbuf + (LT - 1) + s0 * B;
+        auto row = [&](int u) -> v2f * {
+            if constexpr (FIRM)
+                return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
+            else
+                return fbw + u * B;
+        };
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
-        if constexpr (DUMP) {
+        if constexpr (FIRM) {
+            // r = c + g n (m:292-293) as two-sample rows into the wave's private rows: samples
+            // [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
+            const int jl = 8 * llq + 2 * usq, LW = SPW * B;
+            const bool all_full = !DUMP && LW == 128 * NT;
+            v2f *rxb = reinterpret_cast<v2f *>(Hp + PRE + s0 * B) + jl;
+            const int dlt = (plen - 4 * B) / 2;
+            v2f *sink = reinterpret_cast<v2f *>(const_cast<int *>(flags) + 24);   // 16 idle bytes
+#pragma unroll
+            for (int G = 0; G < NT; ++G) {
+                const int jr = 128 * G + jl;
+                const bool valid = all_full || jr < LW;
+                const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
+                const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
+                v2f *dst = rxb + 128 * G + (jr >= 2 * B ? dlt : 0);
+                if (!all_full) dst = valid ? dst : sink;
+                *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
+                if (DUMP && p.dump.rx) {
+                    float2 *dr = valid ? p.dump.rx + s0 * B + jr : p.dump.sink;
+                    const v2f e0 = r0 * p.dump_unscale_rx, e1 = r1 * p.dump_unscale_rx;
+                    dr[0] = make_float2(e0.x, e0.y);
+                    dr[valid ? 1 : 0] = make_float2(e1.x, e1.y);
+                }
+            }
+        } else if constexpr (DUMP) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const bool live = is_main && r < cnt;
@@ -1340,7 +1595,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (r < cnt) fbw[lane * RB + r] = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
             }
         }
-        if (DUMP && p.dump.gain && tid == 0) p.dump.gain[0] = g;
+        if (DUMP && p.dump.gain && tid == 0) p.dump.gain[0] = g * p.dump_unscale_rx;
         wave_sync();
 
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
@@ -1348,7 +1603,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int h2 = delta >> 1;
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
-            const v2f *fb = fbw + (sym_of(u) - s0) * B;
+            const v2f *fb = row(sym_of(u) - s0);
 #pragma unroll
             for (int q = 0; q < VB; ++q) {
                 if (owns(q)) {
@@ -1367,7 +1622,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-        if constexpr (QW) fft_qw<-1>(v, fbw + usq * B, tw, llq);
+        if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
         else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
 
         if (DUMP && p.dump.Y) {
@@ -1378,7 +1633,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if (owns(q))
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            p.dump.Y[sym_of(u) * N + sub_of(q, r)] = make_float2(v[u][q][r].x, v[u][q][r].y);
+                            p.dump.Y[sym_of(u) * N + sub_of(q, r)] = make_float2(v[u][q][r].x * (FIRM ? p.dump_unscale_rx : 1.f),
+                                                                                  v[u][q][r].y * (FIRM ? p.dump_unscale_rx : 1.f));
                 }
         }
         if (QW && wv == 0) {
@@ -1386,7 +1642,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // wave waits for its equaliser.  Those 16 lanes only hand their Y0 and packed labels
             // over (through G itself and the pilot's now idle frame slice); all 64 lanes then
             // form G, four subcarriers each.
-            uint32_t *plab = reinterpret_cast<uint32_t *>(fbw);
+            uint32_t *plab = reinterpret_cast<uint32_t *>(row(0));
             if (usq == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1540,9 +1796,11 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
     }
     if constexpr (N == 256) {
-        if ((spw == 4 || spw == 5) && var <= WOFDM_VAR_ALLOC) {
+        if (spw >= 4 && spw <= 7 && var <= WOFDM_VAR_ALLOC) {
             if (spw == 4) return var ? pick_mode<N, K, 4, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
-            return var ? pick_mode<N, K, 5, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 5, WOFDM_VAR_PLAIN>(mode);
+            if (spw == 5) return var ? pick_mode<N, K, 5, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 5, WOFDM_VAR_PLAIN>(mode);
+            if (spw == 6) return var ? pick_mode<N, K, 6, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 6, WOFDM_VAR_PLAIN>(mode);
+            return var ? pick_mode<N, K, 7, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 7, WOFDM_VAR_PLAIN>(mode);
         }
     }
     return nullptr;
