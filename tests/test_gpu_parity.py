@@ -224,6 +224,22 @@ def test_frame_ranges_add_up_bit_exactly(channels):
     assert (np.diff(ber) <= 0).all() and (np.diff(ber[:8]) < 0).all() and ber[0] > 0.2 and ber[-1] < 1e-3
 
 
+def test_repeatable_at_baseline_scale(channels):
+    """The C2 launch of bench.py, twice: identical counters, and no bit error at 45 / 50 dB -- one
+    corrupted frame there would show as hundreds.  (Guards the matrix-pipe FIR's instruction-order
+    hazard found in round 2, which only appeared as a few wrong frames in 10^4 under load.)"""
+    st = W.make_structure("wtx", 256, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.arange(-5.0, 51.0, 5.0).astype(np.float32)
+    cfg = W.make_cfg(st, 4, 16, 21, 1, 12, 1, seed=2)
+    with W.Plan(cfg, w_tx, w_rx, channels[:1].astype(np.complex64), snrs) as plan:
+        a = plan.run(0, 62500)
+        b = plan.run(0, 62500)
+    assert np.array_equal(a, b)
+    assert a[0, -1, 0, 0] == 0 and a[0, -2, 0, 0] == 0
+    assert a[0, 0, 0, 1] == 62500 * 15 * 256 * 4
+
+
 def test_awgn_textbook_ber_full_size():
     """Size-independent property at BASELINE scale: identity channel, rectangular windows,
     QPSK: BER must follow Q(sqrt(snr_eff)) with the one-symbol pilot doubling the noise."""

@@ -50,6 +50,11 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
+// developer switch: instruction order of the matrix-pipe FIR tiles (see phase B)
+#ifndef WOFDM_FIRM_SCHED
+#define WOFDM_FIRM_SCHED 3
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -575,10 +580,11 @@ __device__ __forceinline__ v2f box_muller(uint32_t a, uint32_t b)
 // One block of stream `stream` of (seed, cell, frame), Philox4x32-10 as in philox.h with the
 // three-input XORs fused (v_bitop3_b32) and the round keys advanced by scalar adds per call
 // (opaque key: otherwise the 20 round keys sit in SGPRs for the whole frame loop).
+template <bool LAUNDER = true>
 __device__ __forceinline__ philox_out stream_block(uint32_t block, uint32_t f_lo, uint32_t f_hi,
                                                    uint32_t stream_cell, uint32_t k0, uint32_t k1)
 {
-    asm volatile("" : "+s"(k0), "+s"(k1));
+    if constexpr (LAUNDER) asm volatile("" : "+s"(k0), "+s"(k1));
     uint32_t c0 = block, c1 = f_lo, c2 = f_hi, c3 = stream_cell;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -618,11 +624,19 @@ __device__ __forceinline__ float wave_sum(float x)
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// (same scheme for the error counters: no lane-index vectors, which the compiler would hoist out of
+// the frame loop and spill)
 __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    auto dpp = [](unsigned v, auto ctrl) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, true);
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});
+    x += dpp(x, std::integral_constant<int, 0x4E>{});
+    x += dpp(x, std::integral_constant<int, 0x141>{});
+    x += dpp(x, std::integral_constant<int, 0x140>{});
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 0) + (unsigned)__builtin_amdgcn_readlane((int)x, 16)
+           + (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
 }
 
 // Spin until the LDS word reaches `target` (monotonic iteration counter written by another wave
@@ -856,16 +870,20 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #endif
     for (; n_items != 0; --n_items) {
         STAMP(7);                                   // loop control, cell changes
-        if (cell != cur_cell) {
+        // the 32-bit per-lane and per-wave error sums are flushed every 2^14 frames at the latest (a wave
+        // counts at most 6144 bit errors per frame)
+        if (cell != cur_cell || nfr == (1u << 14)) {
             if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
             cur_cell = cell;
             if (pair != cur_pair) {
                 __syncthreads();
                 // 1/N of the IDFT (dftmtx(N)'/N, m:370) is folded into the Tx window copy
                 const int P = gm[WOFDM_G_P], delta = gm[WOFDM_G_DELTA];
-                for (int i = tid; i < P; i += blockDim.x)
+                int t0 = tid;                      // (opaque: keeps the fill loops' addresses out of
+                asm volatile("" : "+v"(t0));       // the frame loop's live set)
+                for (int i = t0; i < P; i += blockDim.x)
                     wtx[i] = g_wtx[(size_t)pair * P + i] * p.tx_scale;
-                for (int i = tid; i < N + delta; i += blockDim.x)
+                for (int i = t0; i < N + delta; i += blockDim.x)
                     wrx[i] = g_wrx[(size_t)pair * (N + delta) + i];
                 __syncthreads();
                 cur_pair = pair;
@@ -1301,6 +1319,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const bool all_full = !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
         const v2f zero2 = mk(0.f, 0.f);
         v2f pn2 = zero2, ps2 = zero2;
+        // (the round keys are made opaque once per phase here: they may sit in SGPRs for the tile loop,
+        // not for the whole frame loop)
+        uint32_t key0 = seed_lo, key1 = seed_hi;
+        asm volatile("" : "+s"(key0), "+s"(key1));
         auto noise_pair = [&](int j, bool v0, bool v1, v2f &n0, v2f &n1) {   // samples j (even), j + 1
             if (INJECT) {
                 const float2 *src = p.unit_noise + inj * NL + j;
@@ -1313,35 +1335,69 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if (v1) n1 = ldg2(src + 1);
                 }
             } else {
-                const philox_out o = stream_block((uint32_t)j >> 1, f_lo, f_hi,
-                                                  (WOFDM_STREAM_NOISE << 28) | cell, seed_lo, seed_hi);
+                const philox_out o = stream_block<WOFDM_FIRM_SCHED < 2>((uint32_t)j >> 1, f_lo, f_hi,
+                                                  (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
                 n0 = box_muller(o.w[0], o.w[1]);
                 n1 = box_muller(o.w[2], o.w[3]);
             }
         };
-        auto fir_tile = [&](const uint32_t *b) -> f4 {     // b = plane-H word of x[first output - 24] + 4 g
-            const h8 h0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b));
-            const h8 h1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + 16));
-            const h8 l0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen));
-            const h8 l1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen + 16));
-            f4 d = {0.f, 0.f, 0.f, 0.f};
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], h0, d, 0, 0, 0);      // h_lo x_hi
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], h1, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], l0, d, 0, 0, 0);      // h_hi x_lo
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], l1, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], h0, d, 0, 0, 0);      // h_hi x_hi
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], h1, d, 0, 0, 0);
+        struct bops { h8 h0, h1, l0, l1; };
+        auto fir_load = [&](const uint32_t *b) -> bops {   // b = plane-H word of x[first output - 24] + 4 g
+            bops o;
+            o.h0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b));
+            o.h1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + 16));
+            o.l0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen));
+            o.l1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen + 16));
+            return o;
+        };
+        // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC, the form the matrix
+        // pipe forwards back to back).  Written as a single asm block on purpose: left to the register
+        // allocator the chain hops between accumulators (vDst != SrcC), and with the unit-noise draw
+        // scheduled right behind it, FIR outputs came out sporadically wrong (a few frames in 10^4, run
+        // to run different: tools/racecheck.py) -- also with an in-place chain as six separate asm
+        // statements, i.e. whenever VALU instructions sat between the dependent MFMAs.  Back to back
+        // the chain is exact and repeatable.  The leading s_nop covers a VALU write of an operand just
+        // in front, the trailing one the result's latency and the operand reads of the last MFMA.
+        auto fir_mma = [&](const bops &o) -> f4 {
+            f4 d;
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %5, 0\n\t"        // h_lo x_hi
+                         "v_mfma_f32_16x16x32_f16 %0, %2, %6, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %3, %7, %0\n\t"       // h_hi x_lo
+                         "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %3, %5, %0\n\t"       // h_hi x_hi
+                         "v_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\t"
+                         "s_nop 7"
+                         : "=&v"(d)
+                         : "v"(A[1]), "v"(A[3]), "v"(A[0]), "v"(A[2]), "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1));
             return d;
         };
+        auto fir_tile = [&](const uint32_t *b) -> f4 { return fir_mma(fir_load(b)); };
         // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
         const uint32_t *bh = Hp + jw + 8 * llq + 4 * usq;
+#if WOFDM_FIRM_SCHED >= 3
+        bops bq = fir_load(bh);
+#endif
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
             const bool valid = all_full || jr < LW;
             v2f n0, n1;
+#if WOFDM_FIRM_SCHED >= 3
+            // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
+            // the next tile's operand rows are requested in between
+            const bops bcur = bq;
+            const f4 d = fir_mma(bcur);
+            if (G + 1 < NT) bq = fir_load(bh + 128 * (G + 1));
+            noise_pair(jw + jr, valid, valid, n0, n1);
+#elif WOFDM_FIRM_SCHED >= 1
+            // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile
+            const f4 d = fir_tile(bh + 128 * G);
+            noise_pair(jw + jr, valid, valid, n0, n1);
+#else
             noise_pair(jw + jr, valid, valid, n0, n1);
             const f4 d = fir_tile(bh + 128 * G);
+#endif
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
             nz[2 * G] = n0; nz[2 * G + 1] = n1;
             acc[2 * G] = c0; acc[2 * G + 1] = c1;
