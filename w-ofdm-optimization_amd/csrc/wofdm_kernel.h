@@ -80,15 +80,19 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // (spw is the kernel's layout id: symbols per wave, or 5 = four symbols with 20 outputs per lane)
 // 6 / 7 = four symbols per wave with the FIR on the matrix pipe (wofdm_firm_tiles tiles of 128
 // samples per wave, two samples per lane and tile)
-static inline bool wofdm_is_firm(int spw) { return spw == 6 || spw == 7; }
+// 8 = one symbol per wave with the FIR on the matrix pipe (N >= 512; wofdm_fir8_tiles tiles per wave)
+static inline bool wofdm_is_firm(int spw) { return spw >= 6 && spw <= 8; }
 static inline int wofdm_firm_tiles(int spw) { return spw == 7 ? 10 : 9; }
+static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
+#define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
 #define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
 static inline int wofdm_rb(int n_fft, int spw = 1)
 {
+    if (spw == 8) return 2 * wofdm_fir8_tiles(n_fft);
     if (wofdm_is_firm(spw)) return 2 * wofdm_firm_tiles(spw);
     return spw == 1 ? n_fft / 64 + 1 : (spw == 5 ? 20 : spw * (n_fft / 64) + 2);
 }
-static inline int wofdm_nsym(int spw) { return (spw == 5 || wofdm_is_firm(spw)) ? 4 : spw; }
+static inline int wofdm_nsym(int spw) { return spw == 8 ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw); }
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
@@ -104,6 +108,8 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
+    // one symbol per wave, matrix-pipe FIR: 16-byte operand rows must not straddle a symbol (B % 4)
+    if (firm && plain && n_fft >= 512 && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return 8;
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
@@ -118,6 +124,7 @@ static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
 // and zeros up to the end of the tile that covers the trailing samples behind the last wave.
 static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
+    if (spw == 8) return (8 + 2 * S * B + 2 * WOFDM_FIR8_VT) / 2;
     if (wofdm_is_firm(spw))
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;

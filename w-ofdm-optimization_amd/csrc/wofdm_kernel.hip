@@ -50,11 +50,6 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
-// developer switch: instruction order of the matrix-pipe FIR tiles (see phase B)
-#ifndef WOFDM_FIRM_SCHED
-#define WOFDM_FIRM_SCHED 3
-#endif
-
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -686,7 +681,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = LAY >= 6 ? (LAY == 7 ? 20 : 18)
+    static constexpr int RB = LAY == 8 ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 7 ? 20 : 18)
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -707,18 +702,20 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int LAY, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__(LAY >= 4 ? 256 : 1024 / LAY, LAY >= 4 ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(LAY == 8 ? 1024 : (LAY >= 4 ? 256 : 1024 / LAY), (LAY >= 4 && LAY != 8) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
                     const uint32_t *__restrict__ g_amask, const float2 *__restrict__ g_tmask,
                     const uint4 *__restrict__ g_fira)
 {
-    constexpr int SPW = LAY >= 5 ? 4 : LAY;                  // symbols per wave
-    // layouts 6, 7: quarter-wave layout with the 21-tap FIR on the matrix pipe as a block-Toeplitz
-    // product (NT tiles of 128 samples per wave; see phase B)
-    constexpr bool FIRM = LAY >= 6;
-    constexpr int NT = LAY == 7 ? 10 : 9, PRE = WOFDM_FIRM_PRE;
+    // layouts 6, 7 (quarter-wave, four symbols per wave) and 8 (one symbol per wave, N >= 512): the
+    // 21-tap FIR on the matrix pipe as a block-Toeplitz product, NT tiles of 128 samples per wave (phase B)
+    constexpr bool FIRQ = LAY == 6 || LAY == 7, FIR8 = LAY == 8, FIRM = FIRQ || FIR8;
+    constexpr int SPW = FIR8 ? 1 : (LAY >= 5 ? 4 : LAY);     // symbols per wave
+    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 7 ? 10 : 9), PRE = WOFDM_FIRM_PRE;
+    constexpr int VT = WOFDM_FIR8_VT;
+    static_assert(!FIR8 || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -771,6 +768,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // hi / lo halves (re | im << 16) of sample i - PRE, Lp = Hp + plen (plen = gm[WOFDM_G_FBUF]); the fall
     // tails likewise (tH, tL).  Wave w's four symbol rows of B words in EACH plane double as its
     // private scratch: 2 x 4B words = four rows of B complex floats (row()).
+    // Layout 8 interleaves the planes row by row instead: 8 zero words, then per symbol s B words of
+    // plane H and B words of plane L (word 8 + 2 B s: the wave's private row of B complex floats is
+    // one piece), then a short virtual row S (VT + VT words) for the last symbol's fall tail.
     uint32_t *Hp = reinterpret_cast<uint32_t *>(smem + L::off_fbuf);
     uint32_t *tH = reinterpret_cast<uint32_t *>(smem + L::off_tail), *tL = tH + 16 * L::TAIL_MAX;
 
@@ -959,12 +959,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], mu = gq[WOFDM_G_MU], rho = gq[WOFDM_G_RHO];
-        const int plen = FIRM ? gq[WOFDM_G_FBUF] : 0;
-        v2f *fbw = fbuf + (LT - 1) + s0 * B;       // this wave's SPW symbol slices of the frame
+        const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
+        // this wave's SPW symbol slices of the frame
+        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
         // private row of B complex floats of the wave's symbol slot u (scratch of the transforms,
         // later the received block)
         auto row = [&](int u) -> v2f * {
-            if constexpr (FIRM)
+            if constexpr (FIRQ)
                 return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
             else
                 return fbw + u * B;
@@ -1068,7 +1069,43 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         };
-        if constexpr (FIRM) {
+        if constexpr (FIR8) {
+            // one symbol per wave, rows of plane H and plane L side by side; the fall tail goes to the
+            // tail planes, the last symbol's into the virtual row behind the frame
+            const int s = s0;
+            uint32_t *hrow = Hp + 8 + 2 * B * s;
+            const bool lastsym = s == S - 1;
+            const int DtH = lastsym ? B : (L::off_tail - L::off_fbuf) / 4 + s * L::TAIL_MAX - B - (8 + 2 * B * s);
+            const int DtL = lastsym ? B + VT : DtH + 16 * L::TAIL_MAX;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                const int j = lane + 64 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = j + r * NQ;
+                    const v2f x = v[0][q][r];
+                    auto put_plain = [&](int i) {
+                        uint32_t hi, lo;
+                        split_h(x * wtx[i], hi, lo);
+                        hrow[i] = hi;
+                        hrow[i + B] = lo;
+                    };
+                    auto put_tail = [&](int i) {
+                        uint32_t hi, lo;
+                        split_h(x * wtx[i], hi, lo);
+                        const bool tl = i >= B;
+                        hrow[i + (tl ? DtH : 0)] = hi;
+                        hrow[i + (tl ? DtL : B)] = lo;
+                    };
+                    if (rho < gq[WOFDM_G_BETA]) put_tail(t + mu);
+                    else put_plain(t + mu);
+                    if (63 + 64 * q + r * NQ >= N - L::CPCS_MAX)
+                        if (t >= N - mu) put_plain(t + mu - N);
+                    if (64 * q + r * NQ < L::CPCS_MAX)
+                        if (t < rho) put_tail(t + mu + N);
+                }
+            }
+        } else if constexpr (FIRQ) {
             // the same copies, every sample split into its two packed-f16 words; the fall tail goes to
             // the tail planes, DtH / DtL words away from the row's word in plane H / L
             const int s = s0 + usq;
@@ -1284,20 +1321,30 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // host in MFMA layout) come from L2; the B operands are 16-byte rows of the f16 planes.
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
-        const int plen = gq[WOFDM_G_FBUF];
+        const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
         const int W = S / SPW;
         uint32_t *Lp = Hp + plen;
+        const int ln = lane & 15, lg = lane >> 4;       // MFMA column / row group of the lane
         int ch_now = __builtin_amdgcn_readfirstlane(ch);
         asm volatile("" : "+s"(ch_now));
         const u4 *fa = reinterpret_cast<const u4 *>(g_fira) + (size_t)ch_now * 256 + lane;
         h8 A[4];                                   // [2 half + part]: window half 0/1, h_hi / h_lo
 #pragma unroll
         for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(h8, fa[64 * a]);
-        {
+        if constexpr (FIR8) {
             // overlap-add of the previous symbol's fall tail (m:253-259), in fp32, re-split
-            const int s = s0 + usq;
-            if (s > 0 && llq < beta) {
-                const int idx = PRE + s * B + llq, it = (s - 1) * L::TAIL_MAX + llq;
+            if (s0 > 0 && lane < beta) {
+                uint32_t *hw = Hp + 8 + 2 * B * s0 + lane;
+                const int it = (s0 - 1) * L::TAIL_MAX + lane;
+                uint32_t hi, lo;
+                split_h(join_h(hw[0], hw[B]) + join_h(tH[it], tL[it]), hi, lo);
+                hw[0] = hi;
+                hw[B] = lo;
+            }
+        } else {
+            const int s = s0 + lg;
+            if (s > 0 && ln < beta) {
+                const int idx = PRE + s * B + ln, it = (s - 1) * L::TAIL_MAX + ln;
                 uint32_t hi, lo;
                 split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
                 Hp[idx] = hi;
@@ -1309,12 +1356,20 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             __syncthreads();
             if (p.dump.tx)
                 for (int i = tid; i < gq[WOFDM_G_T]; i += blockDim.x) {
-                    const v2f t = join_h(Hp[PRE + i], Lp[PRE + i]) * p.dump_unscale_tx;
+                    v2f t;
+                    if constexpr (FIR8) {
+                        const int sy = min(i / B, S), off = i - sy * B;
+                        const uint32_t *hw = Hp + 8 + 2 * B * sy + off;
+                        t = join_h(hw[0], hw[sy == S ? VT : B]);
+                    } else {
+                        t = join_h(Hp[PRE + i], Lp[PRE + i]);
+                    }
+                    t = t * p.dump_unscale_tx;
                     p.dump.tx[i] = make_float2(t.x, t.y);
                 }
             __syncthreads();
         }
-        const int jl = 8 * llq + 2 * usq;               // the lane's samples of a tile: jl, jl + 1
+        const int jl = 8 * ln + 2 * lg;                 // the lane's samples of a tile: jl, jl + 1
         const int jw = s0 * B, LW = SPW * B;
         const bool all_full = !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
         const v2f zero2 = mk(0.f, 0.f);
@@ -1335,19 +1390,52 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if (v1) n1 = ldg2(src + 1);
                 }
             } else {
-                const philox_out o = stream_block<WOFDM_FIRM_SCHED < 2>((uint32_t)j >> 1, f_lo, f_hi,
-                                                  (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
+                const philox_out o = stream_block<false>((uint32_t)j >> 1, f_lo, f_hi,
+                                                         (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
                 n0 = box_muller(o.w[0], o.w[1]);
                 n1 = box_muller(o.w[2], o.w[3]);
             }
         };
         struct bops { h8 h0, h1, l0, l1; };
-        auto fir_load = [&](const uint32_t *b) -> bops {   // b = plane-H word of x[first output - 24] + 4 g
+        auto ld16 = [](const uint32_t *q) { return __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(q)); };
+        // operand rows of the tile whose first output is sample `first` of the frame (wave-uniform):
+        // four 16-byte rows = samples first - 24 + 4 lg + 16 half + (0..3) of column ln, both planes
+        auto fir_load = [&](int first, int G, bool trailing) -> bops {
             bops o;
-            o.h0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b));
-            o.h1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + 16));
-            o.l0 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen));
-            o.l1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(b + plen + 16));
+            if constexpr (FIR8) {
+                // the wave's own symbol row, or the virtual row S for the trailing tile.  Window samples
+                // in front of the row (tile 0 only) are the last ones of the previous symbol's rows, or
+                // the zero words in front of symbol 0.
+                const int sy = trailing ? S : s0;
+                const uint32_t *rh = Hp + 8 + 2 * B * sy;
+                const int loff = sy == S ? VT : B;
+                // (columns without a sample read the last column that has one: the trailing tile stays
+                // inside the short virtual row, the wave's last tile inside the frame)
+                int lc = ln;
+                if (trailing) lc = min(ln, 5);
+                else if (G == NT - 1) lc = min(ln, max(0, (B - 128 * (NT - 1) + 7) / 8 - 1));
+                const int q0 = 128 * G + 8 * lc + 4 * lg - 24;
+                const uint32_t *ph0 = rh + q0, *pl0 = rh + loff + q0, *ph1 = ph0 + 16, *pl1 = pl0 + 16;
+                if (G == 0) {
+                    const bool z = sy == 0;
+                    if (q0 < 0) { ph0 = z ? Hp : rh + q0 - B; pl0 = z ? Hp : rh + q0; }
+                    if (q0 + 16 < 0) { ph1 = z ? Hp : rh + q0 + 16 - B; pl1 = z ? Hp : rh + q0 + 16; }
+                }
+                o.h0 = ld16(ph0); o.h1 = ld16(ph1); o.l0 = ld16(pl0); o.l1 = ld16(pl1);
+                if (G == NT - 1 && !trailing) {
+                    // The block that holds the symbol's last samples may reach up to 4 samples past
+                    // them (B is a multiple of 4, not of 8).  The Toeplitz entries that meet those are
+                    // zero, but the words there are another row's (possibly the next wave's scratch:
+                    // any bit pattern, NaN included) -- zero them.
+                    const h8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (q0 >= B) { o.h0 = zr; o.l0 = zr; }
+                    if (q0 + 16 >= B) { o.h1 = zr; o.l1 = zr; }
+                }
+            } else {
+                // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
+                const uint32_t *b = Hp + first + 128 * G + 8 * ln + 4 * lg;
+                o.h0 = ld16(b); o.h1 = ld16(b + 16); o.l0 = ld16(b + plen); o.l1 = ld16(b + plen + 16);
+            }
             return o;
         };
         // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC, the form the matrix
@@ -1372,34 +1460,27 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                          : "v"(A[1]), "v"(A[3]), "v"(A[0]), "v"(A[2]), "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1));
             return d;
         };
-        auto fir_tile = [&](const uint32_t *b) -> f4 { return fir_mma(fir_load(b)); };
-        // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
-        const uint32_t *bh = Hp + jw + 8 * llq + 4 * usq;
-#if WOFDM_FIRM_SCHED >= 3
-        bops bq = fir_load(bh);
-#endif
+        f4 *nscr = nullptr;                         // large DFTs: the unit noise is parked in HBM scratch
+        if constexpr (RENOISE)
+            nscr = reinterpret_cast<f4 *>(p.noise_scratch) + ((size_t)blockIdx.x * 16 + wv) * (NT * 64) + lane;
+        bops bq = fir_load(jw, 0, false);
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
             const bool valid = all_full || jr < LW;
             v2f n0, n1;
-#if WOFDM_FIRM_SCHED >= 3
             // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
             // the next tile's operand rows are requested in between
             const bops bcur = bq;
             const f4 d = fir_mma(bcur);
-            if (G + 1 < NT) bq = fir_load(bh + 128 * (G + 1));
+            if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
             noise_pair(jw + jr, valid, valid, n0, n1);
-#elif WOFDM_FIRM_SCHED >= 1
-            // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile
-            const f4 d = fir_tile(bh + 128 * G);
-            noise_pair(jw + jr, valid, valid, n0, n1);
-#else
-            noise_pair(jw + jr, valid, valid, n0, n1);
-            const f4 d = fir_tile(bh + 128 * G);
-#endif
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
-            nz[2 * G] = n0; nz[2 * G + 1] = n1;
+            if constexpr (RENOISE) {
+                if (!INJECT) nscr[64 * G] = (f4){n0.x, n0.y, n1.x, n1.y};
+            } else {
+                nz[2 * G] = n0; nz[2 * G + 1] = n1;
+            }
             acc[2 * G] = c0; acc[2 * G + 1] = c1;
             // (selects, not branches: columns behind the wave's samples may hold anything)
             const v2f a0 = valid ? c0 : zero2, a1 = valid ? c1 : zero2;
@@ -1433,7 +1514,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const bool v0 = jl < tail_total, v1 = jl + 1 < tail_total;
             v2f n0, n1;
             noise_pair(jt + jl, v0, v1, n0, n1);
-            const f4 d = fir_tile(Hp + jt + 8 * llq + 4 * usq);
+            const f4 d = fir_mma(fir_load(jt, 0, true));
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
             const v2f a0 = v0 ? c0 : zero2, a1 = v1 ? c1 : zero2;
             const v2f m0 = v0 ? n0 : zero2, m1 = v1 ? n1 : zero2;
@@ -1456,6 +1537,20 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         float ps = ps2.x + ps2.y, pn = pn2.x + pn2.y;
         ps = wave_sum(ps); pn = wave_sum(pn);
         if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
+        if constexpr (RENOISE) {
+            // the parked noise comes back HERE, after the FIR's registers have died: the HBM/L2
+            // latency of the reload runs under the wait at barrier 2 instead of opening phase C
+#pragma unroll
+            for (int G = 0; G < NT; ++G) {
+                if (INJECT) {
+                    const bool valid = 128 * G + jl < LW;
+                    noise_pair(jw + 128 * G + jl, valid, valid, nz[2 * G], nz[2 * G + 1]);
+                } else {
+                    const f4 t = nscr[64 * G];
+                    nz[2 * G] = mk(t.x, t.y); nz[2 * G + 1] = mk(t.z, t.w);
+                }
+            }
+        }
         } else {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
@@ -1599,10 +1694,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
         const int gam = gq[WOFDM_G_GAMMA], kap = gq[WOFDM_G_KAPPA];
         const int W = S / SPW;
-        const int plen = FIRM ? gq[WOFDM_G_FBUF] : 0;
-        v2f *fbw = fbuf + (LT - 1) + s0 * B;
+        const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
+        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
         auto row = [&](int u) -> v2f * {
-            if constexpr (FIRM)
+            if constexpr (FIRQ)
                 return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
             else
                 return fbw + u * B;
@@ -1611,12 +1706,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         if constexpr (FIRM) {
-            // r = c + g n (m:292-293) as two-sample rows into the wave's private rows: samples
-            // [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
-            const int jl = 8 * llq + 2 * usq, LW = SPW * B;
+            // r = c + g n (m:292-293) as two-sample rows into the wave's private rows.  Quarter-wave
+            // layouts: samples [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
+            const int jl = 8 * (lane & 15) + 2 * (lane >> 4), LW = SPW * B;
             const bool all_full = !DUMP && LW == 128 * NT;
-            v2f *rxb = reinterpret_cast<v2f *>(Hp + PRE + s0 * B) + jl;
-            const int dlt = (plen - 4 * B) / 2;
+            v2f *rxb = (FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B)) + jl;
+            const int dlt = FIR8 ? 0 : (plen - 4 * B) / 2;
             v2f *sink = reinterpret_cast<v2f *>(const_cast<int *>(flags) + 24);   // 16 idle bytes
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
@@ -1624,7 +1719,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const bool valid = all_full || jr < LW;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
-                v2f *dst = rxb + 128 * G + (jr >= 2 * B ? dlt : 0);
+                v2f *dst = rxb + 128 * G + (!FIR8 && jr >= 2 * B ? dlt : 0);
                 if (!all_full) dst = valid ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
                 if (DUMP && p.dump.rx) {
@@ -1850,6 +1945,10 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
     if (spw == 1) return pick_var<N, K, 1>(mode, var);
     if constexpr (N <= 256) {
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
+    }
+    if constexpr (N >= 512) {
+        if (spw == 8 && var <= WOFDM_VAR_ALLOC)
+            return var ? pick_mode<N, K, 8, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 8, WOFDM_VAR_PLAIN>(mode);
     }
     if constexpr (N == 256) {
         if (spw >= 4 && spw <= 7 && var <= WOFDM_VAR_ALLOC) {
