@@ -146,13 +146,19 @@ int wofdm_plan_set_tx_mask(wofdm_plan *plan, const float *mask);
 /* Health of the plan's finished launches (call after synchronising the stream; copies one
  * word back): WOFDM_OK, or WOFDM_E_HIP if a kernel reported that a wave gave up waiting for its
  * workgroup -- the counters of that plan are then not to be used.  The synchronous entry points
- * (wofdm_run, wofdm_run_injected, wofdm_plan_launch_timed) check it themselves.  Kernels report
- * only when the library is built with -DWOFDM_CHECKED_SYNC=1 (the waits are bounded either way). */
+ * (wofdm_run, wofdm_run_injected, wofdm_plan_launch_timed) check it themselves. */
 int wofdm_plan_status(wofdm_plan *plan);
 
 /* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
  * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
 int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
+
+/* Which instantiation of the frame kernel the plan launches: {layout id, variant}.  Layout: 1, 2 =
+ * one / two symbols per wave with the FIR on the VALU; 4, 5 = four symbols per wave (N = 256), FIR on
+ * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 8 = one symbol per wave (N >= 512), FIR on
+ * the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
+ * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
+int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
 
 /* One-shot, host pointers in / host counters out (synchronous):
  * counts[pairs][n_snr][n_channels][4] accumulated into. */

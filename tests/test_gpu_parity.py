@@ -373,3 +373,128 @@ def test_production_kernels_sharp_parity(channels, system, n_fft, cp, k, S):
     assert want[..., 0].min() > 5e3
     d = np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64))
     assert d.max() <= 12, d
+
+
+# ---------------------------------------------------------------------------------------------
+# Every production (non-instrumented) instantiation of the frame kernel that the compiler gave a
+# non-zero ScratchSize -- the committed build table profiles/r02_kernel_table.json
+# (tools/kernel_table.py) -- is run once at sharp-parity size: register spills inside the divergent
+# regions of these kernels are the hazard DESIGN.md section 4 records, and a reload of the wrong lanes
+# would move the error count by hundreds.  Generate and injected mode, plain / allocation / both
+# Tx-mask forms; the plan must really have picked the instantiation (wofdm_plan_kernel_id).
+def _spilling_kernels():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "..", "profiles", "r02_kernel_table.json")
+    rows = json.load(open(path))["kernels"]
+    return [(r["n_fft"], r["k"], r["layout"], r["inject"], r["var"]) for r in rows
+            if not r["dump"] and r["private_segment_fixed_size"] > 0]
+
+
+def _geometry_for(n_fft, layout, var):
+    """(system, cp, S, environment switches) that make wofdm_plan_create pick `layout`."""
+    env = {}
+    if layout == 1:
+        if n_fft >= 512:
+            env["WOFDM_FIR_VALU"] = "1"
+            return "WOLA", 32, 16, env
+        return ("wtx", 32 if n_fft == 256 else 16, 16 if var >= 2 else 9, env)   # a mask forces one symbol per wave
+    if layout == 2:
+        env.update(WOFDM_FIR_VALU="1", WOFDM_SPW_CAP="2")
+        return "wtx", 32 if n_fft == 256 else 16, 16, env
+    if layout in (4, 5):
+        env["WOFDM_FIR_VALU"] = "1"
+        return ("wtx" if layout == 4 else "CPW"), 32, 16, env        # strides 288 / 293
+    if layout in (6, 7):
+        return "wtx", (32 if layout == 6 else 48), 16, env              # strides 288 / 304
+    assert layout == 8
+    return "WOLA", 32, 16, env
+
+
+@pytest.mark.parametrize("n_fft,k,layout,inject,var", _spilling_kernels())
+def test_every_spilling_production_kernel(channels, monkeypatch, n_fft, k, layout, inject, var):
+    import torch
+    from wofdm_amd import channel_mask as CM
+    system, cp, S, env = _geometry_for(n_fft, layout, var)
+    if var == 2 and n_fft <= 256:
+        env["WOFDM_TXMASK_DIRECT"] = "1"
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.array([5.0, 15.0, 25.0], np.float32) + (k - 4) * 3.0     # BER 0.3 ... 0.01 for every k
+    bits = 1e6 if var >= 2 else (2e6 if inject else 4e6)
+    F = max(4, int(bits / ((S - 1) * n_fft * k)))
+    seed, off = 8, 3
+    cfg = W.make_cfg(st, k, S, 21, 2, 3, 1, seed=seed)
+    h = channels[11:13].astype(np.complex64)
+    rs = np.random.RandomState(n_fft + 7 * k + layout)
+    active = None
+    if var >= 1:
+        active = rs.rand(n_fft) < 0.6
+        active[0] = True
+    mask = CM.tx_mask(st.sym_len, roll_off=10) if var >= 2 else None
+    osys = O.make_sys(n_fft, k, S, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm, st.circ_shift, 21, 1,
+                      active=active, tx_mask=None if mask is None else mask.astype(np.float32).astype(np.float64))
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        if active is not None:
+            plan.set_allocation(active)
+        if mask is not None:
+            plan.set_tx_mask(mask)
+        assert plan.kernel_id() == (layout, var), (plan.kernel_id(), layout, var)
+        if inject:
+            # the oracle's own Philox draws, handed over as injected data
+            nl = O.noise_len(osys)
+            labels = np.zeros((6, F, S, n_fft), np.uint8)
+            noise = np.zeros((6, F, nl), np.complex64)
+            for cell in range(6):
+                for f in range(F):
+                    labels[cell, f] = O.gen_labels(osys, seed, cell, off + f)
+                    noise[cell, f] = O.gen_noise(osys, seed, cell, off + f)
+            counts = plan.new_counts()
+            dl = torch.from_numpy(labels).cuda()
+            dn = torch.from_numpy(noise.view(np.float32).reshape(6, F, nl, 2)).cuda()
+            plan.launch_injected(F, dl, dn, counts)
+            torch.cuda.synchronize()
+            plan.status()
+            got = counts.cpu().numpy().view(np.uint64)
+        else:
+            got = plan.run(off, F)
+    want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128),
+                 snrs.astype(np.float64), seed, off, F)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    assert want[..., 0].min() > 2e2
+    d = np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64))
+    assert d.max() <= 12, (d, got[..., 0], want[..., 0])
+
+
+def test_lost_flag_is_reported(channels):
+    """libwofdm_hip_fault.so is the library with one deliberate protocol error (wave 1 of every
+    workgroup skips publishing its symbols in its third frame): the waiting wave must run out of its
+    bounded wait, and the launch must come back as WOFDM_E_HIP -- not as plausible counters."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    lib = os.path.join(root, "w-ofdm-optimization_amd", "libwofdm_hip_fault.so")
+    assert os.path.exists(lib), "make -C w-ofdm-optimization_amd/csrc builds it"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import wofdm_amd as W
+ch = np.load(%r)["h"]
+st = W.make_structure("wtx", 256, 32)
+cfg = W.make_cfg(st, 4, 16, 21, 1, 2, 1, seed=2)
+with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.complex64), [10.0, 20.0]) as plan:
+    assert plan.kernel_id() == (6, 0)
+    ok = plan.run(0, 2)                      # two frames per workgroup at most: the fault is not reached
+    try:
+        plan.run(0, 20000)
+    except W._lib.WofdmError as e:
+        print("CODE", e.code)
+    else:
+        print("NO ERROR")
+""" % (os.path.abspath(root), os.path.abspath(os.path.join(root, "tests", "golden", "channels_vehA.npz")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WOFDM_LIB=lib),
+                         capture_output=True, text=True, timeout=300)
+    assert "CODE -3" in out.stdout, (out.stdout, out.stderr[-2000:])

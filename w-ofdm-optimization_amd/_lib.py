@@ -26,7 +26,7 @@ EXPORTS = (
     "wofdm_plan_create", "wofdm_plan_destroy", "wofdm_plan_launch", "wofdm_plan_launch_timed",
     "wofdm_plan_launch_injected", "wofdm_plan_dump_frame", "wofdm_plan_info", "wofdm_run",
     "wofdm_run_injected", "wofdm_philox_kat", "wofdm_plan_set_allocation",
-    "wofdm_plan_set_tx_mask", "wofdm_plan_status",
+    "wofdm_plan_set_tx_mask", "wofdm_plan_status", "wofdm_plan_kernel_id",
 )
 
 
@@ -103,6 +103,7 @@ def load():
     L.wofdm_plan_launch_injected.argtypes = [vp, u64, vp, vp, vp, vp]
     L.wofdm_plan_dump_frame.argtypes = [vp, C.c_uint32, u64, vp, vp, vp, C.POINTER(Dump)]
     L.wofdm_plan_info.argtypes = [vp, vp]
+    L.wofdm_plan_kernel_id.argtypes = [vp, vp]
     L.wofdm_plan_set_allocation.argtypes = [vp, vp]
     L.wofdm_plan_set_tx_mask.argtypes = [vp, vp]
     L.wofdm_plan_status.argtypes = [vp]

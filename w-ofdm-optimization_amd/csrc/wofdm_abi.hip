@@ -480,6 +480,14 @@ int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
     return WOFDM_OK;
 }
 
+int wofdm_plan_kernel_id(wofdm_plan *pl, int32_t id[2])
+{
+    if (!pl || !id) return fail(WOFDM_E_INVALID, "NULL argument");
+    id[0] = pl->spw;
+    id[1] = pl->var;
+    return WOFDM_OK;
+}
+
 int wofdm_plan_launch(wofdm_plan *pl, uint64_t frame_offset, uint64_t frames_per_cell,
                       uint64_t *counts_dev, void *stream)
 {

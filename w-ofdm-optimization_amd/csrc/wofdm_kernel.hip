@@ -36,12 +36,17 @@
 #ifndef WOFDM_RELAXED_SYNC
 #define WOFDM_RELAXED_SYNC 1
 #endif
-// The flag waits spin a bounded number of times, so a protocol error can never hang the GPU.  With
-// -DWOFDM_CHECKED_SYNC=1 a wave that runs out of budget also marks the plan's status word
-// (wofdm_plan_status); measured cost of carrying that mark through the frame loop: 0.9 % at C2,
-// so release builds leave it out.
+// The flag waits spin a bounded number of times, so a protocol error can never hang the GPU; a wave
+// that runs out of budget marks an LDS word, which becomes bit 0 of the plan's status word when the
+// workgroup retires: wofdm_plan_status and the synchronous entry points then fail with WOFDM_E_HIP
+// instead of returning counters built on stale samples.  (-DWOFDM_CHECKED_SYNC=0 drops the mark.)
 #ifndef WOFDM_CHECKED_SYNC
-#define WOFDM_CHECKED_SYNC 0
+#define WOFDM_CHECKED_SYNC 1
+#endif
+// Fault injection for tests/test_gpu_parity.py::test_lost_flag_is_reported (libwofdm_hip_fault.so
+// only): wave 1 of every workgroup "forgets" to publish its symbols in its third frame.
+#ifndef WOFDM_FAULT_SKIP_FLAG
+#define WOFDM_FAULT_SKIP_FLAG 0
 #endif
 
 // N = 512 / 1024: FFT as 8.8.8 / 16.4.16 with the outer stages in registers (fft_big); 0 = the
@@ -1300,7 +1305,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // ---- "barrier" 1: publish "my symbols are written"; phase B waits for the
             // predecessor wave only (its last L-1 samples and its fall tail)
             wave_sync();
-            post_flag(&flags[wv], iter, lane);
+            if (!(WOFDM_FAULT_SKIP_FLAG && wv == 1 && iter == 3)) post_flag(&flags[wv], iter, lane);
             if (wv > 0) wait_flag(&flags[wv - 1], iter, &flags[20]);
         } else {
             __syncthreads();                                                 // ---- barrier 1

@@ -89,6 +89,12 @@ class Plan:
         return dict(waves_per_workgroup=a[0], lds_bytes=a[1], workgroups=a[2],
                     workgroups_per_cu=a[3], compute_units=a[4])
 
+    def kernel_id(self):
+        """(layout id, variant) of the kernel instantiation in use (``wofdm_plan_kernel_id``)."""
+        a = (C.c_int32 * 2)()
+        _lib.check(self.lib.wofdm_plan_kernel_id(self._h_plan, a))
+        return int(a[0]), int(a[1])
+
     def set_allocation(self, active):
         """Subcarrier allocation (``wofdm_plan_set_allocation``): ``active`` [N] truthy = bin
         carries data; None = every bin (main_channel_mask.m:387-390, 367-369)."""
