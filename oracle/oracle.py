@@ -73,6 +73,7 @@ def lib():
         L.wofdm_oracle_gen_noise.restype = None
         L.wofdm_oracle_run.argtypes = [C.POINTER(OracleSys), C.c_int, C.c_int, C.c_int, dp, dp,
                                        dp, dp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, u64p]
+        L.wofdm_oracle_run_dense.argtypes = L.wofdm_oracle_run.argtypes
         L.wofdm_oracle_fft.argtypes = [C.c_int, C.c_int, dp]
         L.wofdm_oracle_fft.restype = None
         L.wofdm_oracle_threads.restype = C.c_int
@@ -177,8 +178,9 @@ def frame(sys, w_tx, w_rx, h, snr_db, labels, unit_noise, table=None, nearest=Fa
     return counts, st
 
 
-def run(sys, w_tx, w_rx, h, snr_db, seed, frame_offset, frames_per_cell, n_threads=0):
-    """Generate-mode sweep -> counts[pairs][n_snr][n_channels][4] (uint64)."""
+def run(sys, w_tx, w_rx, h, snr_db, seed, frame_offset, frames_per_cell, n_threads=0, dense=False):
+    """Generate-mode sweep -> counts[pairs][n_snr][n_channels][4] (uint64).  dense=True: Tx / Rx as
+    the reference's hoisted dense matrix products instead of FFTs (``wofdm_oracle_run_dense``)."""
     w_tx = np.ascontiguousarray(np.atleast_2d(w_tx), dtype=np.float64)
     w_rx = np.ascontiguousarray(np.atleast_2d(w_rx), dtype=np.float64)
     h = np.ascontiguousarray(np.atleast_2d(h), dtype=np.complex128)
@@ -187,7 +189,8 @@ def run(sys, w_tx, w_rx, h, snr_db, seed, frame_offset, frames_per_cell, n_threa
     assert w_tx.shape[1] == sys.P and w_rx.shape == (n_pairs, sys.n_fft + sys.tail_rx)
     assert h.shape[1] == sys.n_taps
     counts = np.zeros((n_pairs, n_snr, n_ch, 4), dtype=np.uint64)
-    rc = lib().wofdm_oracle_run(C.byref(sys), n_pairs, n_snr, n_ch, w_tx.ctypes.data,
+    fn = lib().wofdm_oracle_run_dense if dense else lib().wofdm_oracle_run
+    rc = fn(C.byref(sys), n_pairs, n_snr, n_ch, w_tx.ctypes.data,
                                 w_rx.ctypes.data, h.ctypes.data, snr_db.ctypes.data,
                                 int(seed), int(frame_offset), int(frames_per_cell),
                                 int(n_threads), counts.ctypes.data)

@@ -149,12 +149,17 @@ static unsigned nearest_label(int M, const double *table, double re, double im)
 
 /* ------------------------------------------------------------------ frame */
 
-int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
-                       const double *w_tx, const double *w_rx,
-                       const double *h, double snr_db,
-                       const double *qam_table, int nearest,
-                       const uint8_t *labels, const double *unit_noise,
-                       uint64_t counts[4], wofdm_oracle_dump *dump)
+/* tx_mat [P][N] and rx_mat [N][B] (complex, row major) non-NULL: the "faithful" cost structure of
+ * the Python reference, which hoists the two dense products W_tx R IDFT and DFT K P V_rx R out of
+ * the frame loop (wofdm_simulation.py:464-471) and applies them as matrix products in every frame
+ * (187-189, 219-222) instead of FFTs.  Same results to fp64 rounding. */
+static int frame_impl(const wofdm_oracle_sys *sys,
+                      const double *w_tx, const double *w_rx,
+                      const double *h, double snr_db,
+                      const double *qam_table, int nearest,
+                      const uint8_t *labels, const double *unit_noise,
+                      uint64_t counts[4], wofdm_oracle_dump *dump,
+                      const double *tx_mat, const double *rx_mat)
 {
     const int N = sys->n_fft, k = sys->bits_per_sc, S = sys->syms_per_frame;
     const int mu = sys->cp, delta = sys->tail_rx;
@@ -204,7 +209,22 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
      * (419-439: CP = last mu samples in front, CS = first rho samples behind),
      * diagonal Tx window; then the overlap-add + serialise of 253-259
      * (wofdm_simulation.py:187-203): symbol s starts at s*B. */
-    if (!sys->tx_mask) {
+    if (!sys->tx_mask && tx_mat) {
+        /* tx_mat @ X, one symbol (column) at a time (wofdm_simulation.py:187-189) */
+        for (s = 0; s < S; s++) {
+            const double *x = X + 2 * (size_t)s * N;
+            for (i = 0; i < P; i++) {
+                const double *row = tx_mat + 2 * (size_t)i * N;
+                double ar = 0.0, ai = 0.0;
+                for (n = 0; n < N; n++) {
+                    ar += row[2 * n] * x[2 * n] - row[2 * n + 1] * x[2 * n + 1];
+                    ai += row[2 * n] * x[2 * n + 1] + row[2 * n + 1] * x[2 * n];
+                }
+                tx[2 * (s * B + i)] += ar;
+                tx[2 * (s * B + i) + 1] += ai;
+            }
+        }
+    } else if (!sys->tx_mask) {
         for (s = 0; s < S; s++) {
             memcpy(xs, X + 2 * (size_t)s * N, sizeof(double) * 2 * N);
             wofdm_oracle_fft(N, +1, xs);
@@ -295,7 +315,21 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
     /* wofdm_rx, main_BER_calculation.m:297-310: remove gamma samples (442-454),
      * Rx window, overlap-and-add fold (336-355), circular shift (313-333), DFT.
      * K*P*V*R collapses to z[t] = sum_{m = t+kappa+delta/2 (mod N)} w[m] y[gamma+m]. */
-    for (s = 0; s < S; s++) {
+    for (s = 0; s < S && rx_mat; s++) {
+        /* rx_mat @ received block (wofdm_simulation.py:219-222) */
+        const double *y = r + 2 * (size_t)s * B;
+        for (n = 0; n < N; n++) {
+            const double *row = rx_mat + 2 * (size_t)n * B;
+            double ar = 0.0, ai = 0.0;
+            for (j = 0; j < B; j++) {
+                ar += row[2 * j] * y[2 * j] - row[2 * j + 1] * y[2 * j + 1];
+                ai += row[2 * j] * y[2 * j + 1] + row[2 * j + 1] * y[2 * j];
+            }
+            Y[2 * ((size_t)s * N + n)] = ar;
+            Y[2 * ((size_t)s * N + n) + 1] = ai;
+        }
+    }
+    for (s = 0; s < S && !rx_mat; s++) {
         const double *y = r + 2 * (size_t)s * B;
         for (t = 0; t < N; t++) {
             int m0 = (t + kap + delta / 2) % N;
@@ -356,6 +390,45 @@ int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
     rc = 0;
 done:
     return rc;
+}
+
+int wofdm_oracle_frame(const wofdm_oracle_sys *sys,
+                       const double *w_tx, const double *w_rx,
+                       const double *h, double snr_db,
+                       const double *qam_table, int nearest,
+                       const uint8_t *labels, const double *unit_noise,
+                       uint64_t counts[4], wofdm_oracle_dump *dump)
+{
+    return frame_impl(sys, w_tx, w_rx, h, snr_db, qam_table, nearest, labels, unit_noise, counts, dump,
+                      NULL, NULL);
+}
+
+/* The hoisted dense operators of the Python reference (wofdm_simulation.py:464-471):
+ *   tx_mat = W_tx R IDFT          [P][N]: tx_mat[i][n] = w_tx[i] e^{+2 pi i src(i) n / N} / N
+ *   rx_mat = DFT K P V_rx R       [N][B]: rx_mat[q][gamma + m] = w_rx[m] e^{-2 pi i q t(m) / N},
+ *                                          t(m) = m - kappa - delta/2 (mod N), m < N + delta */
+static void build_dense(const wofdm_oracle_sys *sys, const double *w_tx, const double *w_rx,
+                        double *tx_mat, double *rx_mat)
+{
+    const int N = sys->n_fft, P = sys_P(sys), B = sys_B(sys);
+    int i, n, m, q;
+    for (i = 0; i < P; i++) {
+        int src = ((i - sys->cp) % N + N) % N;
+        for (n = 0; n < N; n++) {
+            double a = 2.0 * M_PI * (double)(((long)src * n) % N) / N;
+            tx_mat[2 * ((size_t)i * N + n)] = w_tx[i] * cos(a) / N;
+            tx_mat[2 * ((size_t)i * N + n) + 1] = w_tx[i] * sin(a) / N;
+        }
+    }
+    memset(rx_mat, 0, sizeof(double) * 2 * (size_t)N * B);
+    for (m = 0; m < N + sys->tail_rx; m++) {
+        int t = (((m - sys->circ_shift - sys->tail_rx / 2) % N) + N) % N;
+        for (q = 0; q < N; q++) {
+            double a = -2.0 * M_PI * (double)(((long)q * t) % N) / N;
+            rx_mat[2 * ((size_t)q * B + sys->prefix_rm + m)] += w_rx[m] * cos(a);
+            rx_mat[2 * ((size_t)q * B + sys->prefix_rm + m) + 1] += w_rx[m] * sin(a);
+        }
+    }
 }
 
 /* ----------------------------------------------------------------- Philox */
@@ -448,12 +521,13 @@ int wofdm_oracle_threads(void)
  * part: for every (window pair, snr, channel) cell simulate the frames and
  * accumulate integer counters (quirk Q1: the reference keeps only the last
  * frame's BER; we accumulate all of them, like main_channel_mask.m:341-359). */
-int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_channels,
-                     const double *w_tx, const double *w_rx, const double *h,
-                     const double *snr_db, uint64_t seed, uint64_t frame_offset,
-                     uint64_t frames_per_cell, int n_threads, uint64_t *counts)
+static int run_impl(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_channels,
+                    const double *w_tx, const double *w_rx, const double *h,
+                    const double *snr_db, uint64_t seed, uint64_t frame_offset,
+                    uint64_t frames_per_cell, int n_threads, uint64_t *counts, int dense)
 {
     int rc = sys_check(sys);
+    double *tx_mats = NULL, *rx_mats = NULL;
     const int N = sys->n_fft, S = sys->syms_per_frame, L = sys->n_taps;
     const int P = sys_P(sys), NW = N + sys->tail_rx, NL = wofdm_oracle_noise_len(sys);
     const long n_cells = (long)n_pairs * n_snr * n_channels;
@@ -461,6 +535,15 @@ int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_
     int err = 0;
     if (rc) return rc;
     if (n_cells > 0x0FFFFFFFL) return -9;
+    if (dense && !sys->tx_mask) {
+        const size_t tsz = 2 * (size_t)P * N, rsz = 2 * (size_t)N * sys_B(sys);
+        int pr;
+        tx_mats = (double *)malloc(sizeof(double) * tsz * n_pairs);
+        rx_mats = (double *)malloc(sizeof(double) * rsz * n_pairs);
+        if (!tx_mats || !rx_mats) { free(tx_mats); free(rx_mats); return -100; }
+        for (pr = 0; pr < n_pairs; pr++)
+            build_dense(sys, w_tx + (size_t)pr * P, w_rx + (size_t)pr * NW, tx_mats + tsz * pr, rx_mats + rsz * pr);
+    }
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -482,9 +565,11 @@ int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_
             if (!labels || !noise || !local) { err = -100; continue; }
             wofdm_oracle_gen_labels(sys, seed, (uint32_t)cell, frame, labels);
             wofdm_oracle_gen_noise(sys, seed, (uint32_t)cell, frame, noise);
-            e = wofdm_oracle_frame(sys, w_tx + (size_t)pr * P, w_rx + (size_t)pr * NW,
-                                   h + (size_t)ch * L * 2, snr_db[sn], NULL, 0,
-                                   labels, noise, local + 4 * cell, NULL);
+            e = frame_impl(sys, w_tx + (size_t)pr * P, w_rx + (size_t)pr * NW,
+                           h + (size_t)ch * L * 2, snr_db[sn], NULL, 0,
+                           labels, noise, local + 4 * cell, NULL,
+                           tx_mats ? tx_mats + 2 * (size_t)P * N * pr : NULL,
+                           rx_mats ? rx_mats + 2 * (size_t)N * sys_B(sys) * pr : NULL);
             if (e) err = e;
         }
 #pragma omp critical
@@ -494,5 +579,24 @@ int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_
         }
         free(labels); free(noise); free(local);
     }
+    free(tx_mats); free(rx_mats);
     return err;
+}
+
+int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_channels,
+                     const double *w_tx, const double *w_rx, const double *h,
+                     const double *snr_db, uint64_t seed, uint64_t frame_offset,
+                     uint64_t frames_per_cell, int n_threads, uint64_t *counts)
+{
+    return run_impl(sys, n_pairs, n_snr, n_channels, w_tx, w_rx, h, snr_db, seed, frame_offset,
+                    frames_per_cell, n_threads, counts, 0);
+}
+
+int wofdm_oracle_run_dense(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_channels,
+                           const double *w_tx, const double *w_rx, const double *h,
+                           const double *snr_db, uint64_t seed, uint64_t frame_offset,
+                           uint64_t frames_per_cell, int n_threads, uint64_t *counts)
+{
+    return run_impl(sys, n_pairs, n_snr, n_channels, w_tx, w_rx, h, snr_db, seed, frame_offset,
+                    frames_per_cell, n_threads, counts, 1);
 }

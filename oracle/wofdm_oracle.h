@@ -105,6 +105,15 @@ int wofdm_oracle_run(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_
                      uint64_t seed, uint64_t frame_offset, uint64_t frames_per_cell,
                      int n_threads, uint64_t *counts);
 
+/* The same sweep with the reference's own cost structure ("faithful" CPU leg of bench.py): Tx and Rx as
+ * dense matrix products with the operators hoisted out of the frame loop, as the Python reference does
+ * (wofdm_simulation.py:464-471, 187-189, 219-222), instead of FFTs.  Results equal wofdm_oracle_run's to
+ * fp64 rounding (tests/test_oracle_golden.py). */
+int wofdm_oracle_run_dense(const wofdm_oracle_sys *sys, int n_pairs, int n_snr, int n_channels,
+                           const double *w_tx, const double *w_rx, const double *h, const double *snr_db,
+                           uint64_t seed, uint64_t frame_offset, uint64_t frames_per_cell,
+                           int n_threads, uint64_t *counts);
+
 /* Plain DFT helpers exported so tests can check the oracle's FFT against
  * numpy: dir = -1 forward (no scale), +1 inverse (scaled by 1/N). */
 void wofdm_oracle_fft(int n, int dir, double *x /* [n][2] in place */);

@@ -148,6 +148,27 @@ def test_c5_sweep_sample(channels, n_fft, k):
         _close(got, want, tol_frac=2e-4)
 
 
+@pytest.mark.parametrize("system", list(W.SYSTEMS))
+@pytest.mark.parametrize("n_fft", [256, 512, 1024])
+@pytest.mark.parametrize("k", [2, 4, 6])
+def test_c5_full_grid(channels, system, n_fft, k):
+    """BASELINE config C5 as a grid: all 7 structures x {256, 512, 1024} x {QPSK, 16-QAM, 64-QAM} = 63
+    points (wofdm_simulation.py:391-418 / main_BER_calculation.m:467-492 give the structure table),
+    each 2 channels x 2 SNR points x 3 frames against the oracle on the same Philox streams.  At these
+    sizes a single wrong sample in a frame shows: the tolerance is 6 bit errors per cell."""
+    st = W.make_structure(system, n_fft, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snr = np.array([6.0, 22.0], np.float32) + (k - 4) * 3.0
+    h = channels[50:52].astype(np.complex64)
+    cfg = W.make_cfg(st, k, 16, 21, 2, 2, 1, seed=5, frames_per_cell=3)
+    got = W.run_counts(cfg, w_tx, w_rx, h, snr)
+    want = O.run(_osys(st, k, 16, 21), w_tx.astype(np.float64), w_rx.astype(np.float64),
+                 h.astype(np.complex128), snr.astype(np.float64), 5, 0, 3)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    d = np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64))
+    assert d.max() <= 6 and want[0, 0, :, 0].min() > 100, (d, want[..., 0])
+
+
 def test_matlab_script_mirror_end_to_end(channels, tmp_path):
     """main_BER_calculation.m as a function: window .mat files in, ber_results/*.mat out with the
     reference's variable names; curves vs the oracle through the same cell numbering."""

@@ -202,3 +202,17 @@ def test_oracle_under_address_and_ub_sanitizers():
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")
     r = subprocess.run([os.path.join(root, "oracle", "selftest_asan")], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_dense_cost_structure_gives_the_same_counters():
+    """wofdm_oracle_run_dense (bench.py's "faithful" CPU leg: the reference's hoisted tx_mat / rx_mat
+    products, wofdm_simulation.py:464-471) must count exactly what the FFT form counts."""
+    import os
+    import wofdm_amd as W
+    ch = np.load(os.path.join(os.path.dirname(__file__), "golden", "channels_vehA.npz"))["h"][:2]
+    for system, n, cp in (("wtx", 256, 32), ("WOLA", 64, 16), ("CPW", 128, 20), ("wrx", 64, 12)):
+        st = W.make_structure(system, n, cp)
+        osys = O.make_sys(n, 4, 16, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm, st.circ_shift, 21, 1)
+        args = (osys, W.tx_rc_window(st), W.rx_rc_window(st), ch, [5.0, 15.0], 3)
+        a, b = O.run(*args, 2, 6), O.run(*args, 2, 6, dense=True)
+        assert np.array_equal(a, b) and a[..., 0].min() > 0

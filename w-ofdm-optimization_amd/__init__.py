@@ -26,6 +26,7 @@ from . import channel_mask  # noqa: F401
 from .simulation import (Plan, ber_for_window_file, error_rates, make_cfg,  # noqa: F401
                          results_from_counts, run_counts, run_counts_injected, run_simulation,
                          save_ber_results, simulation_fun, wOFDMSystem)
+from ._lib import kernel_source_hash  # noqa: F401
 from .variants import (SYSTEMS, Structure, calculate_parameters, expand_rx_window,  # noqa: F401
                        expand_tx_window, make_structure, rx_rc_window, tx_rc_window)
 

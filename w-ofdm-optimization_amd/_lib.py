@@ -67,6 +67,17 @@ class Dump(C.Structure):
                                           "labels_rx", "gain", "unit_noise")]
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and their build flags: what a committed
+    measurement of the kernel (profiles/hbm_traffic.json) is stamped with."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("wofdm_kernel.hip", "wofdm_kernel.h", "philox.h", "Makefile"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose=False):
     """Compile libwofdm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL

@@ -553,7 +553,7 @@ int wofdm_plan_dump_frame(wofdm_plan *pl, uint32_t cell, uint64_t frame, const u
         if (hipMemset(arena, 0, bytes) != hipSuccess) { rc = fail(WOFDM_E_HIP, "hipMemset failed"); break; }
         wofdm_kparams kp = pl->base;
         unsigned char *ptr = arena;
-        kp.counts = reinterpret_cast<unsigned long long *>(ptr) - 4 * (size_t)cell; ptr += 32;
+        kp.counts = reinterpret_cast<unsigned long long *>(ptr); ptr += 32;    // entry 0 = `cell` (inject_base_cell below)
         float2 *f2 = reinterpret_cast<float2 *>(ptr);
         kp.dump.X = f2; f2 += SN;
         kp.dump.tx = f2; f2 += g.T;

@@ -24,9 +24,9 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   wtx   float [N + CPCS]   Tx window / N      (needs cp + cs <= CPCS_MAX = 128; 64 at N = 1024,
 //                            where the frame buffer leaves no room for more anyway)
 //   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)
-//   tail  float2[16][16]     fall tails         (needs tail_tx <= 16)
 //   lut   float2[64]         QAM constellation by label
 //   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
+//   tail  float2[S][tail_tx] fall tails, behind the frame buffer (then the Tx-mask tables, if any)
 template <int N> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
@@ -35,8 +35,7 @@ template <int N> struct wofdm_lds {
     static constexpr int off_flags = off_sums + 4 * 64;
     static constexpr int off_wtx = off_flags + 4 * 32;
     static constexpr int off_wrx = off_wtx + 4 * (N + CPCS_MAX);
-    static constexpr int off_tail = off_wrx + 4 * (N + TAILRX_MAX);
-    static constexpr int off_lut = off_tail + 8 * 16 * TAIL_MAX;
+    static constexpr int off_lut = off_wrx + 4 * (N + TAILRX_MAX);
     static constexpr int off_fbuf = off_lut + 8 * 64;
 };
 
@@ -49,12 +48,12 @@ enum { WOFDM_G_S, WOFDM_G_MU, WOFDM_G_RHO, WOFDM_G_BETA, WOFDM_G_DELTA, WOFDM_G_
 struct wofdm_kparams {
     uint32_t n_cells;       // cells covered by this launch, starting at first_cell
     uint32_t first_cell;
-    uint32_t inject_base_cell;   // injected arrays are indexed from this cell
+    uint32_t inject_base_cell;   // injected arrays AND the counter array are indexed from this cell
     unsigned lds_bytes;
     uint64_t frames_per_cell, frame_offset;
     uint64_t items_q, items_r;     // (cell, frame) items per workgroup: q, and one more for the first r
     uint32_t seed_lo, seed_hi;
-    unsigned long long *counts;   // [cells][4]
+    unsigned long long *counts;   // [cells][4], entry 0 = cell inject_base_cell
     const uint8_t *labels;  // inject: [cells][frames][S][N]
     const float2  *unit_noise;    // inject: [cells][frames][NL]
     float2 *noise_scratch;        // generate, N >= WOFDM_NOISE_SCRATCH_MIN_N: [grid][16][RB][64]
@@ -129,11 +128,11 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
-static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S = 0, int B = 0)
+static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 32 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64)
-                      + 8 * 16 * 16 + 8 * 64;
-    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B));
+    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 32 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int beta = T - S * B;
+    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
 }
 
 // kernel registry (wofdm_kernel.hip)

@@ -765,7 +765,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     volatile int *flags = reinterpret_cast<volatile int *>(smem + L::off_flags);
     float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
     float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
-    v2f *tailb = reinterpret_cast<v2f *>(smem + L::off_tail);
+    // (fall tails: S rows of tail_tx samples right behind the frame buffer, at a run-time offset that
+    // every phase re-reads: TAILS())
     v2f *qlut = reinterpret_cast<v2f *>(smem + L::off_lut);
     v2f *fbuf = reinterpret_cast<v2f *>(smem + L::off_fbuf);
     const v2f *g_h = reinterpret_cast<const v2f *>(g_h_);
@@ -777,7 +778,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // plane H and B words of plane L (word 8 + 2 B s: the wave's private row of B complex floats is
     // one piece), then a short virtual row S (VT + VT words) for the last symbol's fall tail.
     uint32_t *Hp = reinterpret_cast<uint32_t *>(smem + L::off_fbuf);
-    uint32_t *tH = reinterpret_cast<uint32_t *>(smem + L::off_tail), *tL = tH + 16 * L::TAIL_MAX;
+#define TAILS()                                                                                \
+    const int tail_off = gq[WOFDM_G_FBUF];            /* float2 units from fbuf */                \
+    v2f *tailb = fbuf + tail_off;                                                                 \
+    uint32_t *tH = reinterpret_cast<uint32_t *>(tailb), *tL = tH + gq[WOFDM_G_S] * gq[WOFDM_G_BETA]; \
+    (void)tH; (void)tL; (void)tail_off
 
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     if (tid < 32) flags[tid] = 0;
@@ -795,7 +800,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     }
     // Tx mask: periodic extension of the mask's impulse response behind the frame buffer,
     // rg[t] = g[(t - RG_OFF) mod (2P-1)], so that the stage below indexes it without a modulo
-    v2f *rg = fbuf + gm[WOFDM_G_FBUF];
+    v2f *rg = fbuf + gm[WOFDM_G_FBUF] + gm[WOFDM_G_S] * gm[WOFDM_G_BETA];
     if constexpr (TXMASK) {
         const int Lm = 2 * gm[WOFDM_G_P] - 1;
         for (int t = tid; t < mask_geo<N>::RG_LEN; t += blockDim.x) {
@@ -806,7 +811,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     }
     // Tx mask, FFT form: twiddles of the MF-point transforms and MF_SLOTS scratch rows behind
     // the frame buffer
-    v2f *mtw = fbuf + gm[WOFDM_G_FBUF];
+    v2f *mtw = fbuf + gm[WOFDM_G_FBUF] + gm[WOFDM_G_S] * gm[WOFDM_G_BETA];
     v2f *mscr = mtw + maskfft_geo::MF;
     if constexpr (TXFFT) fill_twiddles<maskfft_geo::MF>(mtw, tid, (int)blockDim.x);
     __syncthreads();
@@ -854,7 +859,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     uint32_t bit_err = 0, sym_err = 0, nfr = 0;
     float nlin = 0.f;
 
-    auto flush = [&](uint32_t c) {
+    auto flush = [&](uint32_t cabs) {
+        const uint32_t c = cabs - p.inject_base_cell;
         const unsigned be = wave_sum_u(bit_err), se = wave_sum_u(sym_err);
         if (lane == 0) {
             atomicAdd(&p.counts[4 * (size_t)c + 0], (unsigned long long)be);
@@ -965,6 +971,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], mu = gq[WOFDM_G_MU], rho = gq[WOFDM_G_RHO];
         const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
+        const int TS = gq[WOFDM_G_BETA];           // row length of the fall-tail buffer
+        TAILS();
         // this wave's SPW symbol slices of the frame
         v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
         // private row of B complex floats of the wave's symbol slot u (scratch of the transforms,
@@ -1050,9 +1058,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int s = s0 + u;
                 v2f *fb = fbw + u * B;
                 const int Bs = (s == S - 1) ? 0x3fffffff : B;
-                // tailb + s TAIL_MAX - (fb + B) in v2f units, from the LDS offsets (a pointer
+                // tailb + s TS - (fb + B) in v2f units, from the LDS offsets (a pointer
                 // difference would be taken on 64-bit generic addresses)
-                const int Dt = (L::off_tail - L::off_fbuf) / 8 + s * L::TAIL_MAX - (LT - 1) - (s + 1) * B;
+                const int Dt = tail_off + s * TS - (LT - 1) - (s + 1) * B;
 #pragma unroll
                 for (int q = 0; q < BPL; ++q) {
                     const int j = lane + 64 * q;
@@ -1080,8 +1088,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int s = s0;
             uint32_t *hrow = Hp + 8 + 2 * B * s;
             const bool lastsym = s == S - 1;
-            const int DtH = lastsym ? B : (L::off_tail - L::off_fbuf) / 4 + s * L::TAIL_MAX - B - (8 + 2 * B * s);
-            const int DtL = lastsym ? B + VT : DtH + 16 * L::TAIL_MAX;
+            const int DtH = lastsym ? B : 2 * tail_off + s * TS - B - (8 + 2 * B * s);
+            const int DtL = lastsym ? B + VT : DtH + S * TS;
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
                 const int j = lane + 64 * q;
@@ -1116,8 +1124,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int s = s0 + usq;
             uint32_t *hrow = Hp + PRE + s * B;
             const int Bs = (s == S - 1) ? 0x3fffffff : B;
-            const int DtH = (L::off_tail - L::off_fbuf) / 4 + s * L::TAIL_MAX - (PRE + (s + 1) * B);
-            const int DtL = DtH + 16 * L::TAIL_MAX - plen;
+            const int DtH = 2 * tail_off + s * TS - (PRE + (s + 1) * B);
+            const int DtL = DtH + S * TS - plen;
             const bool body_tail = rho < gq[WOFDM_G_BETA];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1151,7 +1159,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int s = s0 + usq;
             v2f *fb = fbw + usq * B;
             const int Bs = (s == S - 1) ? 0x3fffffff : B;
-            const int Dt = (L::off_tail - L::off_fbuf) / 8 + s * L::TAIL_MAX - (LT - 1) - (s + 1) * B;
+            const int Dt = tail_off + s * TS - (LT - 1) - (s + 1) * B;
             const bool body_tail = rho < gq[WOFDM_G_BETA];        // only then a body copy can reach the tail
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1184,7 +1192,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int s = s0;
             v2f *fb = fbw;
             const bool last = s == S - 1;
-            const v2f *xt = last ? fb + B : tailb + s * L::TAIL_MAX;
+            const v2f *xt = last ? fb + B : tailb + s * TS;
             v2f *scr = mscr + (wv % SLOTS) * MF;
             v2f y[1][MBPL][4];
             wave_sync();
@@ -1217,7 +1225,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const int n = lane + 64 * q + r * MQ - (P - 1);
                     if (n >= 0 && n < P) {
                         if (n < B || last) fb[n] = y[0][q][r];
-                        else tailb[s * L::TAIL_MAX + (n - B)] = y[0][q][r];
+                        else tailb[s * TS + (n - B)] = y[0][q][r];
                     }
                 }
             __syncthreads();
@@ -1230,7 +1238,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     for (int r = 0; r < 4; ++r) {
                         const int j = lane + 64 * q + r * MQ - (P - 1) - P;
                         if (j >= 0 && j < P - 1) {
-                            v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * L::TAIL_MAX + (j - B);
+                            v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * TS + (j - B);
                             *dst = *dst + y[0][q][r];
                         }
                     }
@@ -1250,7 +1258,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const bool last = s == S - 1;
             // the symbol's row: samples [0, B) in the frame slice, [B, P) in the tail buffer
             // (the last symbol keeps them in the frame buffer)
-            const v2f *xt = last ? fb + B : tailb + s * L::TAIL_MAX;
+            const v2f *xt = last ? fb + B : tailb + s * TS;
             wave_sync();
             v2f y[NO];
 #pragma unroll
@@ -1281,7 +1289,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int n = lane * NO + i;
                 if (n < P) {
                     if (n < B || last) fb[n] = y[i];
-                    else tailb[s * L::TAIL_MAX + (n - B)] = y[i];
+                    else tailb[s * TS + (n - B)] = y[i];
                 }
             }
             __syncthreads();
@@ -1293,7 +1301,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int i = 0; i < NO; ++i) {
                     const int j = lane * NO + i - P;
                     if (j >= 0 && j < P - 1) {
-                        v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * L::TAIL_MAX + (j - B);
+                        v2f *dst = (j < B || nlast) ? fn + j : tailb + (s + 1) * TS + (j - B);
                         *dst = *dst + y[i];
                     }
                 }
@@ -1329,6 +1337,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
         const int W = S / SPW;
         uint32_t *Lp = Hp + plen;
+        TAILS();
         const int ln = lane & 15, lg = lane >> 4;       // MFMA column / row group of the lane
         int ch_now = __builtin_amdgcn_readfirstlane(ch);
         asm volatile("" : "+s"(ch_now));
@@ -1340,7 +1349,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // overlap-add of the previous symbol's fall tail (m:253-259), in fp32, re-split
             if (s0 > 0 && lane < beta) {
                 uint32_t *hw = Hp + 8 + 2 * B * s0 + lane;
-                const int it = (s0 - 1) * L::TAIL_MAX + lane;
+                const int it = (s0 - 1) * beta + lane;
                 uint32_t hi, lo;
                 split_h(join_h(hw[0], hw[B]) + join_h(tH[it], tL[it]), hi, lo);
                 hw[0] = hi;
@@ -1349,7 +1358,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         } else {
             const int s = s0 + lg;
             if (s > 0 && ln < beta) {
-                const int idx = PRE + s * B + ln, it = (s - 1) * L::TAIL_MAX + ln;
+                const int idx = PRE + s * B + ln, it = (s - 1) * beta + ln;
                 uint32_t hi, lo;
                 split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
                 Hp[idx] = hi;
@@ -1561,11 +1570,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
         const int W = S / SPW;                         // waves per workgroup
         v2f *fbw = fbuf + (LT - 1) + s0 * B;
+        TAILS();
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
             const int s = s0 + u;
             v2f *fb = fbw + u * B;
-            if (s > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s - 1) * L::TAIL_MAX + lane];
+            if (s > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s - 1) * beta + lane];
         }
         wave_sync();
         if (DUMP) {

@@ -22,17 +22,41 @@ def frame_shard(total_frames, rank, world_size, frame_offset=0):
     return frame_offset + lo, hi - lo
 
 
-def all_reduce_counts(counts, group=None):
-    """Sum the counter tensor over all ranks in place (no-op without an initialised process
-    group).  ``counts``: int64 torch tensor (device tensor under nccl/RCCL, CPU under gloo)."""
+def _backend(group=None):
+    """Name of the initialised process group's backend ("nccl" = RCCL, "gloo"), or None."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return str(dist.get_backend(group)).lower()
+
+
+def all_reduce_counts(counts, group=None):
+    """Sum the int64 counter tensor over all ranks in place (no-op without an initialised process
+    group).  The tensor is reduced where the backend can reach it: a device tensor directly under
+    nccl (= RCCL over xGMI), through a host copy under gloo; a CPU tensor through a device copy
+    under nccl."""
+    import torch
+    import torch.distributed as dist
+    be = _backend(group)
+    if be is None:
+        return counts
+    if be == "nccl" and not counts.is_cuda:
+        t = counts.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        counts.copy_(t.cpu())
+    elif be != "nccl" and counts.is_cuda:
+        torch.cuda.synchronize(counts.device)
+        t = counts.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        counts.copy_(t)
+    else:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
 
 
 def reduce_counts_numpy(counts, group=None):
-    """Same for a host uint64 ndarray (goes through a CPU int64 tensor)."""
+    """Same for a host uint64 ndarray (through an int64 tensor; under nccl that tensor lives on the
+    current CUDA device for the reduction)."""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(counts).view(np.int64).copy())
     all_reduce_counts(t, group)

@@ -119,7 +119,11 @@ def run_ber_calculation(settings_file="settingsData.mat", windows_folder="optimi
             bits_per_subcar=int(gen["bitsPerSubcarrier"]), symbols_per_tx=int(gen["symbolsPerTx"]),
             ensemble=ensemble, tail_tx=int(tails["tailTx"]), tail_rx=int(tails["tailRx"]),
             seed=seed, device=device, frame_range=shard)
-        counts = D.reduce_counts_numpy(counts, group) if world > 1 else counts
+        if world > 1:
+            if D._backend(group) == "nccl":           # RCCL reduces on this rank's GPU
+                import torch
+                torch.cuda.set_device(device)
+            counts = D.reduce_counts_numpy(counts, group)
         results = S.results_from_counts(type_ofdm, counts)
         if rank == 0:
             S.save_ber_results(results_folder, type_ofdm, cp, results)
