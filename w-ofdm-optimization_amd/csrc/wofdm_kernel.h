@@ -101,9 +101,8 @@ static inline int wofdm_nsym(int spw) { return spw == 8 ? 1 : ((spw == 5 || wofd
 static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool firm = true)
 {
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
-        // matrix-pipe FIR: sample pairs must not straddle a symbol (B even)
-        if (firm && B % 2 == 0 && 4 * B <= 128 * wofdm_firm_tiles(6)) return 6;
-        if (firm && B % 2 == 0 && 4 * B <= 128 * wofdm_firm_tiles(7)) return 7;
+        if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return 6;
+        if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return 7;
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }

@@ -1449,6 +1449,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
                 const uint32_t *b = Hp + first + 128 * G + 8 * ln + 4 * lg;
                 o.h0 = ld16(b); o.h1 = ld16(b + 16); o.l0 = ld16(b + plen); o.l1 = ld16(b + plen + 16);
+                if (G == NT - 1 && !trailing && !all_full) {
+                    // odd strides: the block with the wave's last samples reaches 4 samples into the next
+                    // wave's rows, which may still hold that wave's scratch (0 x NaN): zero those words
+                    const int q0 = 128 * G + 8 * ln + 4 * lg - 24;
+                    const h8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (q0 >= LW) { o.h0 = zr; o.l0 = zr; }
+                    if (q0 + 16 >= LW) { o.h1 = zr; o.l1 = zr; }
+                }
             }
             return o;
         };
