@@ -1775,6 +1775,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
         const int h2 = delta >> 1;
+        // (two passes: all main-tap loads in flight together, free of branches; the folded samples --
+        // at most tail_rx of the N per symbol -- only where there is an Rx tail at all)
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const v2f *fb = row(sym_of(u) - s0);
@@ -1783,14 +1785,27 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (owns(q)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int t = sub_of(q, r);
-                        const int m0 = (t + kap + h2) & (N - 1);
-                        v2f z = fb[gam + m0] * wrx[m0];
-                        if (m0 < delta) {
-                            const float w2 = wrx[m0 + N];
-                            z = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], z);
+                        const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
+                        v[u][q][r] = fb[gam + m0] * wrx[m0];
+                    }
+                }
+            }
+        }
+        if (delta > 0) {
+#pragma unroll
+            for (int u = 0; u < VS; ++u) {
+                const v2f *fb = row(sym_of(u) - s0);
+#pragma unroll
+                for (int q = 0; q < VB; ++q) {
+                    if (owns(q)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
+                            if (m0 < delta) {
+                                const float w2 = wrx[m0 + N];
+                                v[u][q][r] = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], v[u][q][r]);
+                            }
                         }
-                        v[u][q][r] = z;
                     }
                 }
             }
