@@ -61,7 +61,7 @@ def cpu_baseline(W, st, w_tx, w_rx, h, seed, target_s=10.0, dense_s=8.0):
         t0 = time.perf_counter()
         O.run(*args, 0, 4 * threads, n_threads=threads, dense=dense)
         rate = 4 * threads / (time.perf_counter() - t0)                # frames per cell per second
-        frames = int(max(4 * threads, min(20000, rate * budget_s)))
+        frames = int(max(4 * threads, min(60000, rate * budget_s)))
         t0 = time.perf_counter()
         counts = O.run(*args, 0, frames, n_threads=threads, dense=dense)
         dt = time.perf_counter() - t0

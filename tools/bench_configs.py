@@ -34,7 +34,7 @@ def run(system, n_fft, k, n_ch, n_snr, frames, cp=32, S=16, reps=3):
 
 
 if __name__ == "__main__":
-    f = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    f = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000
     run("wtx", 256, 4, 1, 12, 62500)
     for system in W.SYSTEMS:
         run(system, 256, 4, 1, 1, 62500)
@@ -43,3 +43,6 @@ if __name__ == "__main__":
     run("WOLA", 512, 4, 10, 20, f // 2)
     run("WOLA", 1024, 6, 100, 20, max(1, f // 20))
     run("WOLA", 1024, 2, 10, 20, f // 2)
+    if "--c4-full" in sys.argv:
+        # BASELINE config 4 at full size on ONE GPU: 100 channels x 20 SNR points x 62 500 frames = 2e9 symbols
+        run("WOLA", 1024, 6, 100, 20, 62500, reps=1)
