@@ -168,6 +168,16 @@ int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, cons
                        const float *h, const float *snr_db, const uint8_t *labels,
                        const float *unit_noise, uint64_t *counts);
 
+/* Closed-form ICI + ISI power per subcarrier of the structure in cfg, for every (window pair, channel):
+ * power[pairs][n_channels][n_fft] (host, float) = sum_{n' != n} |A_0[n,n']|^2 + sum_{n'} |A_1[n,n']|^2 with
+ * A_m = W K P V_rx R H_m V_tx Gamma W^-1.  Replaces calculate_interference
+ * (matlab/main_interference_calculation.m:177-225; its scalar is the sum over n) and interf_power
+ * (python/ofdm_utils/interf_calc.py:20-113; its np.diag(PISI + PICI1) is power[0][0][:]).  Uses n_fft, cp,
+ * cs, tail_tx, tail_rx, prefix_rm, circ_shift, n_taps, n_channels, n_window_pairs of cfg.
+ * Synchronous; host pointers. */
+int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+                       const float *h, float *power);
+
 /* Philox4x32-10 known-answer hook (runs one block on the GPU). */
 int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -256,3 +256,30 @@ def test_reference_workflow_windows_then_ber_then_mask(channels, tmp_path):
                             str(tmp_path / "pysim")))
     assert os.path.exists(tmp_path / "pysim" / "ser" / "opt_CPwtx_16.npy")
     assert os.path.exists(tmp_path / "pysim" / "ser" / "rc_CPwtx_16.npy")
+
+
+def test_interference_closed_form_on_gpu(golden, channels):
+    """Row f2 on the GPU (wofdm_interference): against the reference's own interf_power output
+    (tests/golden/interference.npz, N = 64, all seven structures), and at N = 256 / 512 / 1024, batched over
+    window pairs and channels, against the host mirror of the same formula (fp64)."""
+    from wofdm_amd import variants as V
+    g = golden("interference.npz")
+    for system in W.SYSTEMS:
+        n_fft, cp, cs, ttx, trx, rm, shift = [int(v) for v in g[system + "_cfg"]]
+        st = V.Structure(system, n_fft, cp, ttx, trx, cs, rm, shift)
+        got = W.interference.interf_power_gpu(st, V.tx_rc_window(st), V.rx_rc_window(st), g["h"])[0, 0]
+        want = g[system + "_P_rc"]
+        assert np.abs(got - want).max() < 2e-5 * np.abs(want).max() + 1e-9, system
+    rs = np.random.RandomState(2)
+    for system, n_fft, cp in (("WOLA", 256, 32), ("CPW", 256, 10), ("wtx", 512, 24), ("wrx", 1024, 32), ("CP", 256, 16)):
+        st = W.make_structure(system, n_fft, cp)
+        xt, xr = _tail_vectors(st, rs)
+        w_tx = np.stack([W.tx_rc_window(st), W.expand_tx_window(st, xt) if st.tail_tx else np.ones(st.sym_len)])
+        w_rx = np.stack([W.rx_rc_window(st), W.expand_rx_window(st, xr) if st.tail_rx else np.ones(st.rx_win_len)])
+        h = channels[3:6]
+        got = W.interference.interf_power_gpu(st, w_tx, w_rx, h)
+        assert got.shape == (2, 3, n_fft)
+        for pi in range(2):
+            for ci in range(3):
+                want = W.interference.interf_power(st, w_tx[pi], w_rx[pi], h[ci])
+                assert np.abs(got[pi, ci] - want).max() < 5e-5 * np.abs(want).max() + 1e-9, (system, pi, ci)

@@ -670,6 +670,56 @@ int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, cons
     return rc;
 }
 
+int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
+                       const float *h, float *power)
+{
+    if (!w_tx || !w_rx || !h || !power) return fail(WOFDM_E_INVALID, "NULL argument");
+    geom g;
+    int rc = check_cfg(cfg, &g);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(WOFDM_E_HIP, "device %d not available (%d visible); there is no CPU fallback", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    const int jobs = cfg->n_window_pairs * cfg->n_channels;
+    const size_t n_wtx = (size_t)cfg->n_window_pairs * g.P, n_wrx = (size_t)cfg->n_window_pairs * (g.N + g.delta);
+    std::vector<float2> hp((size_t)cfg->n_channels * WOFDM_LT, make_float2(0.f, 0.f));
+    for (int c = 0; c < cfg->n_channels; ++c)
+        for (int l = 0; l < g.L; ++l)
+            hp[(size_t)c * WOFDM_LT + l] = make_float2(h[2 * ((size_t)c * g.L + l)], h[2 * ((size_t)c * g.L + l) + 1]);
+    float *d_wtx = nullptr, *d_wrx = nullptr, *d_pow = nullptr;
+    float2 *d_h = nullptr;
+    rc = WOFDM_OK;
+    do {
+        if (hipMalloc(&d_wtx, n_wtx * 4) != hipSuccess || hipMalloc(&d_wrx, n_wrx * 4) != hipSuccess ||
+            hipMalloc(&d_h, hp.size() * 8) != hipSuccess || hipMalloc(&d_pow, (size_t)jobs * g.N * 4) != hipSuccess) {
+            rc = fail(WOFDM_E_NOMEM, "device allocation failed"); break;
+        }
+        if (hipMemcpy(d_wtx, w_tx, n_wtx * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_wrx, w_rx, n_wrx * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_h, hp.data(), hp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "upload failed"); break;
+        }
+        hipError_t e = hipErrorInvalidValue;
+        if (g.N == 64) e = wofdm_interf_launch_n64(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
+        if (g.N == 128) e = wofdm_interf_launch_n128(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
+        if (g.N == 256) e = wofdm_interf_launch_n256(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
+        if (g.N == 512) e = wofdm_interf_launch_n512(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
+        if (g.N == 1024) e = wofdm_interf_launch_n1024(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
+        if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(power, d_pow, (size_t)jobs * g.N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "interference kernel or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (d_wtx) (void)hipFree(d_wtx);
+    if (d_wrx) (void)hipFree(d_wrx);
+    if (d_h) (void)hipFree(d_h);
+    if (d_pow) (void)hipFree(d_pow);
+    return rc;
+}
+
 int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     if (!ctr || !key || !out) return fail(WOFDM_E_INVALID, "NULL argument");

@@ -201,3 +201,13 @@ static inline wofdm_kernel_fn wofdm_select_kernel(int n_fft, int bits_per_sc, in
     return nullptr;
 }
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s);
+// closed-form ICI/ISI power kernels (wofdm_kernel.hip, k = 2 translation units)
+#define WOFDM_INTERF_DECL(n)                                                                                  \
+    hipError_t wofdm_interf_launch_n##n(int jobs, int P, int B, int mu, int delta, int gam, int kap, int n_ch, \
+                                        const float *wtx, const float *wrx, const float2 *h, float *power,     \
+                                        hipStream_t s)
+WOFDM_INTERF_DECL(64);
+WOFDM_INTERF_DECL(128);
+WOFDM_INTERF_DECL(256);
+WOFDM_INTERF_DECL(512);
+WOFDM_INTERF_DECL(1024);

@@ -1944,6 +1944,131 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Closed-form ICI + ISI power of a structure:
+//   calculate_interference  matlab/main_interference_calculation.m:177-225
+//   interf_power            python/ofdm_utils/interf_calc.py:20-113
+//     A_m = W K P V_rx R  H_m  V_tx Gamma W^-1,   H_m[b, c] = h[m B + b - c],   m = 0, 1
+//     P[n] = sum_{n' != n} |A_0[n, n']|^2 + sum_{n'} |A_1[n, n']|^2
+// Column n' of A_m is the frame pipeline's own answer to a unit symbol on subcarrier n': the windowed,
+// CP/CS-extended complex exponential x (the Tx matrix applied to e_n'), the 21-tap convolution over two
+// symbol periods, and per period the Rx window / fold / shift + DFT of the kernels above -- no dense
+// matrices, no RNG.  One workgroup per (window pair, channel) job; a wave takes the columns
+// n' = wave, wave + W, ... and keeps |A|^2 row sums of its subcarriers (FFT output layout) in registers;
+// one LDS reduction over the waves at the end.  (M = 1 + ceil((L - 1 + beta) / B) = 2 for every
+// supported structure: B >= 64 > 36.)
+struct wofdm_iparams {
+    int P, B, mu, delta, gam, kap, n_ch, rowlen;   // rowlen: float2 per wave row (24 + 2B + 24 rounded up)
+    float *power;                                  // [pairs][n_ch][N]
+};
+template <int N> struct interf_geo {
+    static constexpr int WAVES = N <= 256 ? 16 : (N == 512 ? 8 : 4);
+    static constexpr int RB2 = 2 * (N / 64 + 1);                      // FIR outputs per lane over 2B samples
+    static constexpr int CH = RB2 % 6 == 0 ? 6 : (RB2 % 5 == 0 ? 5 : (RB2 % 4 == 0 ? 4 : 2));
+};
+
+template <int N>
+__global__ void __launch_bounds__(interf_geo<N>::WAVES * 64)
+wofdm_interf_kernel(const wofdm_iparams p, const float *__restrict__ g_wtx, const float *__restrict__ g_wrx,
+                    const float2 *__restrict__ g_h_)
+{
+    constexpr int WAVES = interf_geo<N>::WAVES, RB2 = interf_geo<N>::RB2, LT = WOFDM_LT;
+    constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
+    constexpr bool FULL = geo<N>::FULL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: FFT stage twiddles [N] | e^{+2 pi i k / N} [N] | w_rx [N + 64] | per wave: row [rowlen] + scratch [N]
+    v2f *tw = reinterpret_cast<v2f *>(smem);
+    v2f *wn = tw + N;
+    float *wrx = reinterpret_cast<float *>(wn + N);
+    v2f *rows = reinterpret_cast<v2f *>(wrx + N + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x, pair = job / p.n_ch, ch = job - pair * p.n_ch;
+    const int P = p.P, B = p.B;
+    fill_twiddles<N>(tw, tid, WAVES * 64);
+    for (int i = tid; i < N; i += WAVES * 64) {
+        float sv, cv;
+        sincospif(2.0f * (float)i / (float)N, &sv, &cv);
+        wn[i] = mk(cv, sv);
+    }
+    for (int i = tid; i < N + p.delta; i += WAVES * 64) wrx[i] = g_wrx[(size_t)pair * (N + p.delta) + i];
+    v2f *row = rows + (size_t)wv * (p.rowlen + N);
+    v2f *scr = row + p.rowlen;
+    for (int i = lane; i < p.rowlen; i += 64) row[i] = mk(0.f, 0.f);
+    __syncthreads();
+    const v2f *__restrict__ taps = reinterpret_cast<const v2f *>(g_h_) + (size_t)ch * LT;
+    const float *__restrict__ wtx = g_wtx + (size_t)pair * P;
+    float pw[BPL][4];
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[q][r] = 0.f;
+    const int h2 = p.delta >> 1;
+    for (int np = wv; np < N; np += WAVES) {
+        // x[c] = w_tx[c] e^{2 pi i ((c - mu) mod N) n' / N} / N at row[24 + c]  (tx matrix column, m:358-376)
+        for (int c = lane; c < P; c += 64) {
+            const int t = (c - p.mu) & (N - 1);
+            row[24 + c] = wn[(t * np) & (N - 1)] * (wtx[c] * (1.0f / (float)N));
+        }
+        for (int c = P + lane; c < 2 * B + 24; c += 64) row[24 + c] = mk(0.f, 0.f);
+        wave_sync();
+        // z = conv(h, x) over two symbol periods (m:260): lane -> RB2 consecutive outputs from j0
+        v2f acc[RB2];
+        const int j0 = lane * RB2;
+        fir_lane<RB2, interf_geo<N>::CH>(row + 24 - (LT - 1) + j0, taps, acc);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < RB2; ++r)
+            if (j0 + r < 2 * B) row[24 + j0 + r] = acc[r];
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            // Rx window, fold, circular shift (m:297-355) of period m, then the DFT
+            const v2f *fb = row + 24 + m * B;
+            v2f v[1][BPL][4];
+#pragma unroll
+            for (int q = 0; q < BPL; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[0][q][r] = mk(0.f, 0.f);
+                    if (!(FULL || lane + 64 * q < NQ)) continue;
+                    const int m0 = (lane + 64 * q + r * NQ + p.kap + h2) & (N - 1);
+                    v2f z = fb[p.gam + m0] * wrx[m0];
+                    if (m0 < p.delta) {
+                        const float w2 = wrx[m0 + N];
+                        z = __builtin_elementwise_fma(mk(w2, w2), fb[p.gam + m0 + N], z);
+                    }
+                    v[0][q][r] = z;
+                }
+            fft_wave<N, -1, 1>(v, scr, 0, tw, lane);
+#pragma unroll
+            for (int q = 0; q < BPL; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = lane + 64 * q + r * NQ;
+                    const float e = v[0][q][r].x * v[0][q][r].x + v[0][q][r].y * v[0][q][r].y;
+                    if (FULL || lane + 64 * q < NQ)
+                        pw[q][r] += (m == 0 && n == np) ? 0.f : e;    // the wanted term A_0[n, n] is no interference
+                }
+        }
+        wave_sync();
+    }
+    // sum over the waves (each wave's row is free now): float [WAVES][N] in the rows area
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(rows);
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (FULL || lane + 64 * q < NQ) red[wv * N + lane + 64 * q + r * NQ] = pw[q][r];
+    __syncthreads();
+    for (int n = tid; n < N; n += WAVES * 64) {
+        float t = 0.f;
+        for (int w = 0; w < WAVES; ++w) t += red[w * N + n];
+        p.power[(size_t)job * N + n] = t;
+    }
+}
+
 __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
 {
     if (threadIdx.x == 0) {
@@ -2020,6 +2145,27 @@ wofdm_kernel_fn WOFDM_CAT(WOFDM_CAT(WOFDM_CAT(wofdm_select_kernel_n, WOFDM_TU_N)
 {
     return pick<WOFDM_TU_N>(WOFDM_TU_K, spw, mode, var);
 }
+
+#if WOFDM_TU_K == 2
+// one interference kernel per DFT length, compiled in the k = 2 translation units
+hipError_t WOFDM_CAT(wofdm_interf_launch_n, WOFDM_TU_N)(int jobs, int P, int B, int mu, int delta, int gam, int kap,
+                                                        int n_ch, const float *wtx, const float *wrx, const float2 *h,
+                                                        float *power, hipStream_t s)
+{
+    constexpr int N = WOFDM_TU_N, W = interf_geo<N>::WAVES;
+    wofdm_iparams ip;
+    ip.P = P; ip.B = B; ip.mu = mu; ip.delta = delta; ip.gam = gam; ip.kap = kap; ip.n_ch = n_ch;
+    ip.rowlen = (24 + 2 * B + 24 + 64 * interf_geo<N>::RB2 - 2 * B + 1) / 2 * 2;   // covers every lane's FIR window
+    ip.power = power;
+    const size_t lds = 8 * (size_t)N * 2 + 4 * (size_t)(N + 64) + (size_t)W * 8 * (ip.rowlen + N);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wofdm_interf_kernel<N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wofdm_interf_kernel<N>, dim3(jobs), dim3(W * 64), lds, s, ip, wtx, wrx, h);
+    return hipGetLastError();
+}
+#endif
 
 #if WOFDM_TU_N == 64 && WOFDM_TU_K == 2
 hipError_t wofdm_philox_kat_launch(const uint32_t *ctr_key_dev, uint32_t *out_dev, hipStream_t s)

@@ -61,3 +61,25 @@ def interf_power(st, w_tx, w_rx, h):
 def total_interference(st, w_tx, w_rx, h):
     """Scalar of the MATLAB function: tr(offdiag(A0)^H offdiag(A0)) + sum_m tr(A_m^H A_m)."""
     return float(interf_power(st, w_tx, w_rx, h).sum())
+
+
+def interf_power_gpu(st, w_tx, w_rx, h, device=0):
+    """The same per-subcarrier power on the GPU (``wofdm_interference``: the frame kernels' own Tx /
+    FIR / Rx chain applied to the N unit symbols, one workgroup per (window pair, channel)), batched:
+    w_tx [pairs][P], w_rx [pairs][N + tail_rx], h [n_channels][taps]  ->  float32 [pairs][n_channels][N].
+    No CPU fallback."""
+    import ctypes as C
+    from . import _lib
+    from .simulation import make_cfg
+    w_tx = _lib.f32(np.atleast_2d(w_tx))
+    w_rx = _lib.f32(np.atleast_2d(w_rx))
+    hh = np.atleast_2d(np.asarray(h))
+    if w_tx.shape != (w_rx.shape[0], st.sym_len) or w_rx.shape[1] != st.rx_win_len:
+        raise ValueError("window shapes %s / %s do not fit the structure" % (w_tx.shape, w_rx.shape))
+    cfg = make_cfg(st, 4, 16, hh.shape[1], hh.shape[0], 1, w_tx.shape[0])
+    hf = _lib.c64_as_f32(hh, (cfg.n_channels, cfg.n_taps))
+    out = np.zeros((w_tx.shape[0], hh.shape[0], st.n_fft), dtype=np.float32)
+    lib = _lib.load()
+    _lib.check(lib.wofdm_interference(C.byref(cfg), int(device), w_tx.ctypes.data, w_rx.ctypes.data,
+                                      hf.ctypes.data, out.ctypes.data))
+    return out
