@@ -498,7 +498,7 @@ void wofdm_oracle_gen_noise(const wofdm_oracle_sys *sys, uint64_t seed, uint32_t
         double rad, ang;
         if ((j & 1) == 0) stream_block(seed, 1u, cell, frame, (uint32_t)(j >> 1), w);
         u1 = fmaf((float)w[2 * (j & 1)], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-        u2 = (float)w[2 * (j & 1) + 1] * 2.3283064365386963e-10f;
+        u2 = (float)(w[2 * (j & 1) + 1] >> 9) * 1.1920928955078125e-07f;   /* top 23 bits (philox.h) */
         rad = sqrt(-2.0 * log((double)u1));
         ang = 2.0 * M_PI * (double)u2;
         unit_noise[2 * j]     = rad * cos(ang);

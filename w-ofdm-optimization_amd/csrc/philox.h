@@ -11,7 +11,7 @@
 // word (n*kslot >> 5) & 3, shift n*kslot & 31; the label is the low k bits (bit k-1 = first
 // bit of the subcarrier, as qammod's 'bit' input orders them).
 // Noise: block p carries the complex unit normals of samples 2p (words 0,1) and 2p+1
-// (words 2,3): u1 = fma(w_a, 2^-32, 2^-33), u2 = w_b * 2^-32,
+// (words 2,3): u1 = fma(w_a, 2^-32, 2^-33), u2 = (w_b >> 9) * 2^-23 (the top 23 bits),
 // n = sqrt(-2 ln u1) * (cos 2 pi u2 + j sin 2 pi u2).
 #pragma once
 #include <stdint.h>

@@ -567,13 +567,18 @@ __device__ __forceinline__ void fir_chunk(const v2f *w, const v2f *__restrict__ 
     }
 }
 
-// two complex unit normals from one Philox block (philox.h)
-__device__ __forceinline__ v2f box_muller(uint32_t a, uint32_t b)
+// one complex unit normal from two Philox words (philox.h).  The angle uses the top 23 bits of b as the
+// mantissa of a float in [1, 2): v_sin / v_cos take revolutions, so the integer part drops out and no
+// convert + scale is needed.  UNIT = false leaves out the factor sqrt(2 ln 2) of the radius
+// (-2 ln u1 = 2 ln2 * -log2 u1): where the noise only meets its own measured power (g = sqrt(Ps nlin / Pn),
+// r = c + g n) a common factor cancels exactly; WOFDM_NOISE_UNSCALE restores it for stage dumps.
+#define WOFDM_NOISE_UNSCALE 1.1774100225154747f
+template <bool UNIT = true> __device__ __forceinline__ v2f box_muller(uint32_t a, uint32_t b)
 {
     const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float u2 = (float)b * 2.3283064365386963e-10f;
-    // -2 ln(u1) = -2 ln2 log2(u1); v_sin/v_cos take revolutions
-    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    const float u2 = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, b, 9));   // 1 + (b >> 9) 2^-23
+    const float l2 = __builtin_amdgcn_logf(u1);
+    const float rad = UNIT ? __builtin_amdgcn_sqrtf(-1.3862943611198906f * l2) : __builtin_amdgcn_sqrtf(-l2);
     return mk(__builtin_amdgcn_cosf(u2), __builtin_amdgcn_sinf(u2)) * rad;
 }
 
@@ -1406,10 +1411,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             } else {
                 const philox_out o = stream_block<false>((uint32_t)j >> 1, f_lo, f_hi,
                                                          (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
-                n0 = box_muller(o.w[0], o.w[1]);
-                n1 = box_muller(o.w[2], o.w[3]);
+                n0 = box_muller<false>(o.w[0], o.w[1]);
+                n1 = box_muller<false>(o.w[2], o.w[3]);
             }
         };
+        // (generated noise is short of sqrt(2 ln 2), see box_muller: only the dumps care)
+        const float nuns = INJECT ? 1.0f : WOFDM_NOISE_UNSCALE;
         struct bops { h8 h0, h1, l0, l1; };
         auto ld16 = [](const uint32_t *q) { return __builtin_bit_cast(h8, *reinterpret_cast<const u4 *>(q)); };
         // operand rows of the tile whose first output is sample `first` of the frame (wave-uniform):
@@ -1485,11 +1492,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         f4 *nscr = nullptr;                         // large DFTs: the unit noise is parked in HBM scratch
         if constexpr (RENOISE)
             nscr = reinterpret_cast<f4 *>(p.noise_scratch) + ((size_t)blockIdx.x * 16 + wv) * (NT * 64) + lane;
+        // (two instantiations of the tile loop: with every lane of every tile in use -- C2 -- the
+        // validity selects are not even emitted)
+        auto tiles = [&](auto full_c) {
+        constexpr bool FULLT = decltype(full_c)::value;
         bops bq = fir_load(jw, 0, false);
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
-            const bool valid = all_full || jr < LW;
+            const bool valid = FULLT || jr < LW;
             v2f n0, n1;
             // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
             // the next tile's operand rows are requested in between
@@ -1520,11 +1531,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
                 if (p.dump.unit_noise) {
                     float2 *dn = valid ? p.dump.unit_noise + jw + jr : p.dump.sink;
-                    dn[0] = make_float2(n0.x, n0.y);
-                    dn[valid ? 1 : 0] = make_float2(n1.x, n1.y);
+                    dn[0] = make_float2(n0.x * nuns, n0.y * nuns);
+                    dn[valid ? 1 : 0] = make_float2(n1.x * nuns, n1.y * nuns);
                 }
             }
         }
+        };
+        if (all_full) tiles(std::true_type{});
+        else tiles(std::false_type{});
         const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
         if (tail_total > 0 && wv == 0) {
             // the trailing samples of the frame (they only feed the power sums): one more tile, by
@@ -1551,8 +1565,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     *(v1 ? p.dump.conv + jt + jl + 1 : p.dump.sink) = make_float2(e1.x, e1.y);
                 }
                 if (p.dump.unit_noise) {
-                    *(v0 ? p.dump.unit_noise + jt + jl : p.dump.sink) = make_float2(n0.x, n0.y);
-                    *(v1 ? p.dump.unit_noise + jt + jl + 1 : p.dump.sink) = make_float2(n1.x, n1.y);
+                    *(v0 ? p.dump.unit_noise + jt + jl : p.dump.sink) = make_float2(n0.x * nuns, n0.y * nuns);
+                    *(v1 ? p.dump.unit_noise + jt + jl + 1 : p.dump.sink) = make_float2(n1.x * nuns, n1.y * nuns);
                 }
             }
         }
@@ -1769,7 +1783,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (r < cnt) fbw[lane * RB + r] = __builtin_elementwise_fma(mk(g, g), nz[r], acc[r]);
             }
         }
-        if (DUMP && p.dump.gain && tid == 0) p.dump.gain[0] = g * p.dump_unscale_rx;
+        // (undo the signal's scale and, where the generated noise is short of sqrt(2 ln 2), that factor)
+        if (DUMP && p.dump.gain && tid == 0)
+            p.dump.gain[0] = g * p.dump_unscale_rx * ((FIRM && !INJECT) ? 1.0f / WOFDM_NOISE_UNSCALE : 1.0f);
         wave_sync();
 
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
