@@ -1912,31 +1912,37 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                 for (int q = 0; q < VB; ++q) {
                     if (owns(q)) {
+                        // The four subcarriers of a butterfly are demapped together, one byte each of the
+                        // packed words: per-axis level index = rne(clamp(+-x qinv/2 + m1/2)) converted,
+                        // clamped below and packed by v_cvt_pk_u8_f32; binary reflected Gray code on all
+                        // eight fields at once; popcount of the XOR with the packed transmitted labels =
+                        // bit errors, its non-zero bytes = symbol errors.
+                        uint32_t iw = 0, qw = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = sub_of(q, r);
                             const v2f xh = cmul(v[u][q][r], G[n]);
-                            // per-axis slicer: level index = floor((+-x*qinv + m1)/2 + 1/2), both axes
-                            // in one packed fma, floor+convert in one instruction each
                             const v2f lev = __builtin_elementwise_fma(
-                                xh, mk(0.5f * qinv, -0.5f * qinv), mk(0.5f * (float)m1 + 0.5f, 0.5f * (float)m1 + 0.5f));
-                            int ii, qi;
-                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ii) : "v"(lev.x));
-                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(qi) : "v"(lev.y));
-                            ii = min(max(ii, 0), m1);
-                            qi = min(max(qi, 0), m1);
-                            const uint32_t Lrx = ((uint32_t)(ii ^ (ii >> 1)) << half) | (uint32_t)(qi ^ (qi >> 1));
-                            const uint32_t Ltx = (lab[u][q] >> (8 * r)) & 0xFFu;
-                            uint32_t diff = Ltx ^ Lrx;
-                            if constexpr (ALLOC) {
-                                if (Ltx & 0x80u) diff = 0u;              // not loaded: not counted
-                            }
-                            bit_err += __popc(diff);
-                            sym_err += diff != 0u;
-                            if (DUMP) {
-                                if (p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
-                                if (p.dump.labels_rx) p.dump.labels_rx[(s - 1) * N + n] = (uint8_t)Lrx;
-                            }
+                                xh, mk(0.5f * qinv, -0.5f * qinv), mk(0.5f * (float)m1, 0.5f * (float)m1));
+                            iw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lev.x, (float)m1), r, iw);
+                            qw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lev.y, (float)m1), r, qw);
+                            if (DUMP && p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
+                        }
+                        constexpr uint32_t GM = K == 2 ? 0u : (K == 4 ? 0x05050505u : 0x1B1B1B1Bu);
+                        constexpr uint32_t LM = lmask * 0x01010101u;
+                        const uint32_t cw = (iw << half) | qw;
+                        const uint32_t gw = cw ^ ((cw >> 1) & GM);            // Gray labels, one per byte
+                        uint32_t diff = (gw ^ lab[u][q]) & LM;
+                        if constexpr (ALLOC) {
+                            // bit 7 of a byte = subcarrier not loaded: not counted
+                            diff &= ~(((lab[u][q] >> 7) & 0x01010101u) * 0xFFu);
+                        }
+                        bit_err += __popc(diff);
+                        sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);    // bytes < 64: bit 7 <=> non-zero
+                        if (DUMP && p.dump.labels_rx) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                p.dump.labels_rx[(s - 1) * N + sub_of(q, r)] = (uint8_t)((gw >> (8 * r)) & lmask);
                         }
                     }
                 }
