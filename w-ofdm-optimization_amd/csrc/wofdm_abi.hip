@@ -335,6 +335,10 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
         pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
         PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
+        // developer switch: fill the scratch with NaN patterns, so that a read of something this launch
+        // has not written cannot pass for noise
+        if (const char *ps = std::getenv("WOFDM_POISON_SCRATCH"); ps && ps[0] == '1')
+            PLAN_TRY(hipMemset(pl->d_nscr, 0xFF, pl->nscr_wgs * row * sizeof(float2)));
     }
 #undef PLAN_TRY
     *out = pl;

@@ -1132,31 +1132,49 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int DtH = 2 * tail_off + s * TS - (PRE + (s + 1) * B);
             const int DtL = DtH + S * TS - plen;
             const bool body_tail = rho < gq[WOFDM_G_BETA];
+            // per-lane bases once, element offsets as instruction immediates: sample t + mu of the row
+            // with t = llq + 16 tt sits 16 tt words behind the base; prefix copies N words in front of it
+            uint32_t *pH = hrow + (llq + mu), *pL = pH + plen;
+            const float *pW = wtx + (llq + mu);
+            uint32_t *pHp = pH - N, *pLp = pL - N;
+            const float *pWp = pW - N;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int t = llq + 16 * (q + 4 * r);
+                    const int tt = q + 4 * r, t = llq + 16 * tt;
                     const v2f x = v[0][q][r];
-                    auto put_plain = [&](int i) {
-                        uint32_t hi, lo;
-                        split_h(x * wtx[i], hi, lo);
-                        hrow[i] = hi;
-                        hrow[i + plen] = lo;
-                    };
-                    auto put_tail = [&](int i) {
-                        uint32_t hi, lo;
+                    uint32_t hi, lo;
+                    if (body_tail) {
+                        const int i = t + mu;
                         split_h(x * wtx[i], hi, lo);
                         const bool tl = i >= Bs;
                         hrow[i + (tl ? DtH : 0)] = hi;
                         hrow[i + plen + (tl ? DtL : 0)] = lo;
-                    };
-                    if (body_tail) put_tail(t + mu);
-                    else put_plain(t + mu);
-                    if (15 + 16 * (q + 4 * r) >= N - L::CPCS_MAX)
-                        if (t >= N - mu) put_plain(t + mu - N);
-                    if (16 * (q + 4 * r) < L::CPCS_MAX)
-                        if (t < rho) put_tail(t + mu + N);
+                    } else {
+                        split_h(x * pW[16 * tt], hi, lo);
+                        pH[16 * tt] = hi;
+                        pL[16 * tt] = lo;
+                    }
+                    // (the wave-uniform test first: most elements have no lane in the prefix / suffix)
+                    if (15 + 16 * tt >= N - L::CPCS_MAX)
+                        if (16 * tt + 15 >= N - mu) {
+                            if (t >= N - mu) {
+                                split_h(x * pWp[16 * tt], hi, lo);
+                                pHp[16 * tt] = hi;
+                                pLp[16 * tt] = lo;
+                            }
+                        }
+                    if (16 * tt < L::CPCS_MAX)
+                        if (16 * tt < rho) {
+                            if (t < rho) {
+                                const int i = t + mu + N;
+                                split_h(x * wtx[i], hi, lo);
+                                const bool tl = i >= Bs;
+                                hrow[i + (tl ? DtH : 0)] = hi;
+                                hrow[i + plen + (tl ? DtL : 0)] = lo;
+                            }
+                        }
                 }
         } else if constexpr (QW) {
             // the same copies with per-lane symbol geometry (the four quarters of the wave sit in
@@ -1575,7 +1593,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
         if constexpr (RENOISE) {
             // the parked noise comes back HERE, after the FIR's registers have died: the HBM/L2
-            // latency of the reload runs under the wait at barrier 2 instead of opening phase C
+            // latency of the reload runs under the wait at barrier 2 instead of opening phase C.
+            // The wave first waits for its own stores to be acknowledged: on the first launch of a plan
+            // (cold TLB / L2 for the fresh scratch buffer) a few frames came back with other noise than
+            // they had stored -- counters off by tens, once in two fresh processes, never afterwards.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 if (INJECT) {
