@@ -391,6 +391,26 @@ def _spilling_kernels():
             if not r["dump"] and r["private_segment_fixed_size"] > 0]
 
 
+def _poison():
+    import ctypes
+    import os
+    W._lib.load()                                       # (one HIP runtime per process: the library first)
+    path = os.path.join(os.path.dirname(__file__), "..", "w-ofdm-optimization_amd", "libwofdm_poison.so")
+    lib = ctypes.CDLL(path)
+    lib.scratch_poison.argtypes = [ctypes.c_uint32]
+    return lib
+
+
+def test_scratch_poison_tool_works():
+    """The helper's own check: a kernel that reads a scratch array it never wrote must see the pattern."""
+    import ctypes
+    lib = _poison()
+    out = np.zeros(64 * 1024, np.uint32)
+    assert lib.scratch_poison(0x7FC0DEAD) == 0
+    assert lib.scratch_peek(out.ctypes.data_as(ctypes.c_void_p), 64) == 0
+    assert (out == 0x7FC0DEAD).all()
+
+
 def _geometry_for(n_fft, layout, var):
     """(system, cp, S, environment switches) that make wofdm_plan_create pick `layout`."""
     env = {}
@@ -442,6 +462,9 @@ def test_every_spilling_production_kernel(channels, monkeypatch, n_fft, k, layou
         if mask is not None:
             plan.set_tx_mask(mask)
         assert plan.kernel_id() == (layout, var), (plan.kernel_id(), layout, var)
+        # every scratch slot of the queue filled with a NaN pattern: a spill slot reloaded without having
+        # been written in this launch cannot pass for the value an earlier launch left there
+        assert _poison().scratch_poison(0x7FC0DEAD) == 0
         if inject:
             # the oracle's own Philox draws, handed over as injected data
             nl = O.noise_len(osys)

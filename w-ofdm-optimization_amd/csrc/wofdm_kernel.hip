@@ -861,12 +861,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     const uint32_t seed_hi = __builtin_amdgcn_readfirstlane(p.seed_hi);
     uint32_t cur_cell = 0xFFFFFFFFu;
     int cur_pair = -1;
+    // Error counters of the cell in progress: per-lane partial sums, or -- at N >= 512, where the
+    // kernels are at their VGPR limit and per-lane accumulators ended up in scratch, re-read and
+    // re-written every frame -- wave totals in scalar registers (one DPP reduction per frame).
+    constexpr bool SCALAR_ACC = N >= 512;
     uint32_t bit_err = 0, sym_err = 0, nfr = 0;
     float nlin = 0.f;
 
     auto flush = [&](uint32_t cabs) {
         const uint32_t c = cabs - p.inject_base_cell;
-        const unsigned be = wave_sum_u(bit_err), se = wave_sum_u(sym_err);
+        const unsigned be = SCALAR_ACC ? bit_err : wave_sum_u(bit_err), se = SCALAR_ACC ? sym_err : wave_sum_u(sym_err);
         if (lane == 0) {
             atomicAdd(&p.counts[4 * (size_t)c + 0], (unsigned long long)be);
             atomicAdd(&p.counts[4 * (size_t)c + 2], (unsigned long long)se);
@@ -1344,6 +1348,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(1);
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
+        // (large DFTs: the lane id is made opaque again per phase, or per-lane index vectors of one
+        // phase's FFT are kept for the next phase's FFT -- in scratch, at the 128-VGPR limit)
+        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
         if constexpr (FIRM) {
         // The 21-tap complex FIR as a block-Toeplitz product on the matrix pipe.  One
         // v_mfma_f32_16x16x32_f16 tile = 8 consecutive outputs (re and im rows interleaved: 16 rows)
@@ -1514,7 +1521,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // validity selects are not even emitted)
         auto tiles = [&](auto full_c) {
         constexpr bool FULLT = decltype(full_c)::value;
-        bops bq = fir_load(jw, 0, false);
+        // (N = 1024 is at its 128-VGPR limit: no operand prefetch there, the rows are requested per tile)
+        constexpr bool PREFETCH = true;
+        bops bq;
+        if constexpr (PREFETCH) bq = fir_load(jw, 0, false);
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
@@ -1522,9 +1532,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             v2f n0, n1;
             // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
             // the next tile's operand rows are requested in between
+            if constexpr (!PREFETCH) bq = fir_load(jw, G, false);
             const bops bcur = bq;
             const f4 d = fir_mma(bcur);
-            if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
+            if constexpr (PREFETCH) {
+                if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
+            }
             noise_pair(jw + jr, valid, valid, n0, n1);
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
             if constexpr (RENOISE) {
@@ -1593,12 +1606,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (lane == 0) { sums_it[wv] = ps; sums_it[16 + wv] = pn; }
         if constexpr (RENOISE) {
             // the parked noise comes back HERE, after the FIR's registers have died: the HBM/L2
-            // latency of the reload runs under the wait at barrier 2 instead of opening phase C.
-            // The wave first waits for its own stores to be acknowledged: on the first launch of a plan
-            // (cold TLB / L2 for the fresh scratch buffer) a few frames came back with other noise than
-            // they had stored -- counters off by tens, once in two fresh processes, never afterwards.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+            // latency of the reload runs under the wait at barrier 2 instead of opening phase C
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 if (INJECT) {
@@ -1749,6 +1757,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(3);
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
+        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
         {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
@@ -1928,6 +1937,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(5);
 
         // ------------------------------------------------------------ D: equalise, demap, count
+        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
+        uint32_t be_f = 0, se_f = 0;                   // this frame's errors of the lane (SCALAR_ACC)
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const int s = sym_of(u);
@@ -1960,8 +1971,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             // bit 7 of a byte = subcarrier not loaded: not counted
                             diff &= ~(((lab[u][q] >> 7) & 0x01010101u) * 0xFFu);
                         }
-                        bit_err += __popc(diff);
-                        sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);    // bytes < 64: bit 7 <=> non-zero
+                        // (bytes < 64: bit 7 of byte + 0x7F <=> byte non-zero)
+                        if constexpr (SCALAR_ACC) {
+                            be_f += __popc(diff);
+                            se_f += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
+                        } else {
+                            bit_err += __popc(diff);
+                            sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
+                        }
                         if (DUMP && p.dump.labels_rx) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -1972,6 +1989,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
 
+        if constexpr (SCALAR_ACC) {
+            bit_err += wave_sum_u(be_f);
+            sym_err += wave_sum_u(se_f);
+        }
         STAMP(6);
         if (++fidx == F) { fidx = 0; next_cell(); }
     }
