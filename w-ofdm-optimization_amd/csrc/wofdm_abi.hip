@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -99,6 +100,11 @@ struct wofdm_plan {
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
     uint4 *d_fira = nullptr;           // [n_ch][4][64] Toeplitz operands of the matrix-pipe FIR (MFMA A layout)
     float firm_sx = 1.f, firm_sh = 1.f; // powers of two carried by the f16 samples / f16 taps there
+    // Kernels with register spills (ScratchSize > 0): the first launch on a stream is preceded by a
+    // one-frame launch of the same kernel into a dummy counter (see launch()).
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    std::vector<std::pair<hipStream_t, int>> warmed;   // (stream, mode) pairs already warmed
+    unsigned long long *d_warm = nullptr;
     int occ = 1, cus = 1, spw = 1;     // spw: layout id of the kernels in use (wofdm_spw)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -134,7 +140,11 @@ int configure(wofdm_plan *pl)
                         var, masked ? " (the Tx mask needs n_fft <= 512)" : "");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn[m]),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn[m])));
+        pl->scratch_bytes[m] = fa.localSizeBytes;
     }
+    pl->warmed.clear();
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw), lds));
@@ -178,6 +188,27 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     kp.tx_scale = pl->base.tx_scale;
     kp.dump_unscale_tx = pl->base.dump_unscale_tx;
     kp.dump_unscale_rx = pl->base.dump_unscale_rx;
+    // Spilling kernels only.  In a fresh process the FIRST launch of a kernel with scratch gave counters
+    // off by tens (a few frames) in 4 of 9 runs of the N = 1024 kernel while it still had 60 B of
+    // scratch -- never on a later launch, never with ScratchSize 0, and the kernel does not read scratch it
+    // has not written (tests poison the scratch memory).  That points at the queue's scratch memory being
+    // set up under the first dispatch that needs it; so that dispatch is made a throw-away one here: one
+    // frame of the same kernel with the same inputs into a dummy counter, once per (stream, mode).
+    if (pl->scratch_bytes[mode] > 0 && mode < WOFDM_MODE_DUMP_GEN) {
+        bool seen = false;
+        for (auto &w : pl->warmed) seen = seen || (w.first == stream && w.second == mode);
+        if (!seen) {
+            if (!pl->d_warm) HIP_TRY(hipMalloc(&pl->d_warm, 4 * sizeof(unsigned long long)));
+            wofdm_kparams wp = kp;
+            wp.counts = pl->d_warm; wp.n_cells = 1; wp.first_cell = kp.inject_base_cell;
+            wp.frames_per_cell = 1; wp.items_q = 1; wp.items_r = 0;
+            void *wargs[] = {&wp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
+                             &pl->d_fira};
+            HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3(1u),
+                                    dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), wargs, kp.lds_bytes, stream));
+            pl->warmed.emplace_back(stream, mode);
+        }
+    }
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
                     &pl->d_fira};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
@@ -335,10 +366,14 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
         pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
         PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
-        // developer switch: fill the scratch with NaN patterns, so that a read of something this launch
-        // has not written cannot pass for noise
-        if (const char *ps = std::getenv("WOFDM_POISON_SCRATCH"); ps && ps[0] == '1')
-            PLAN_TRY(hipMemset(pl->d_nscr, 0xFF, pl->nscr_wgs * row * sizeof(float2)));
+        // The buffer is touched once here, on the host's time: the first launch of a plan in a fresh
+        // process otherwise returned counters off by tens at N = 1024 (the only size that parks noise here)
+        // in about four of ten runs, never a later launch -- and not once with this fill in place.
+        // (WOFDM_POISON_SCRATCH=1, developer switch: NaN patterns instead of zeros, so that a read of
+        // something this launch has not written cannot pass for noise.)
+        const char *ps = std::getenv("WOFDM_POISON_SCRATCH");
+        PLAN_TRY(hipMemset(pl->d_nscr, (ps && ps[0] == '1') ? 0xFF : 0, pl->nscr_wgs * row * sizeof(float2)));
+        PLAN_TRY(hipDeviceSynchronize());
     }
 #undef PLAN_TRY
     *out = pl;
@@ -360,6 +395,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
     if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->d_fira) (void)hipFree(pl->d_fira);
+    if (pl->d_warm) (void)hipFree(pl->d_warm);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;

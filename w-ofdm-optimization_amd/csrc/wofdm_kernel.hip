@@ -746,6 +746,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // HBM scratch row ([wave][r][lane]: 512-byte coalesced rows, written and read back by the
     // same lane, L2-resident) instead of registers; with injected noise it is simply re-read.
     constexpr bool RENOISE = N >= WOFDM_NOISE_SCRATCH_MIN_N;
+    // Kernels at their VGPR limit make the lane id opaque again at every phase: otherwise per-lane index
+    // vectors of one phase's FFT are kept for the next phase's -- in scratch (N = 1024: 20 spilled VGPRs
+    // -> 0).  Elsewhere the recomputation costs more than it saves (N = 512: -2.5 %; C2 would spill).
+    constexpr bool RELAUNDER = N >= 1024 || (N >= 512 && VAR >= 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -1350,7 +1354,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
         // (large DFTs: the lane id is made opaque again per phase, or per-lane index vectors of one
         // phase's FFT are kept for the next phase's FFT -- in scratch, at the 128-VGPR limit)
-        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
+        if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         if constexpr (FIRM) {
         // The 21-tap complex FIR as a block-Toeplitz product on the matrix pipe.  One
         // v_mfma_f32_16x16x32_f16 tile = 8 consecutive outputs (re and im rows interleaved: 16 rows)
@@ -1757,7 +1761,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(3);
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
-        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
+        if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
@@ -1937,7 +1941,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(5);
 
         // ------------------------------------------------------------ D: equalise, demap, count
-        if constexpr (N >= 1024) asm volatile("" : "+v"(lane));
+        if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         uint32_t be_f = 0, se_f = 0;                   // this frame's errors of the lane (SCALAR_ACC)
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
