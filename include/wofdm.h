@@ -178,6 +178,16 @@ int wofdm_run_injected(const wofdm_cfg *cfg, int device, const float *w_tx, cons
 int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, const float *w_rx,
                        const float *h, float *power);
 
+/* Tx-side spectrum estimate: the waveform of no_symbols consecutive symbols X[no_symbols][n_fft][2] (host,
+ * complex values on the bins, zeros on unloaded ones) through IDFT, CP/CS copy, Tx window w_tx[P] and the
+ * overlap-add of `overlap` tail samples (tail_tx for the Tx-windowed structures, 0 otherwise), then the sum
+ * over consecutive slices of 8 n_fft samples (zero-padded remainder included) of |FFT|^2, fftshift-ed:
+ * psd[8 n_fft] (host).  Replaces the Tx chain and psd_estimate of wOFDMSystem.estimate_obr
+ * (python/ofdm_utils/timefreq_simulation.py:242-258, 101-123); the caller divides by the reference's slice
+ * count (full slices + 1).  Uses n_fft, cp, cs of cfg; n_fft in {64, 128, 256}.  Synchronous. */
+int wofdm_tx_psd(const wofdm_cfg *cfg, int device, const float *w_tx, const float *X, int no_symbols,
+                 int overlap, float *psd);
+
 /* Philox4x32-10 known-answer hook (runs one block on the GPU). */
 int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

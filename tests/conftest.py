@@ -33,6 +33,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_report_header(config):
+    # which GPU the -m gpu run was on (a transient first-launch deviation seen in round 2 is tracked per device)
+    if "gpu" not in (config.getoption("-m") or "") or "not gpu" in (config.getoption("-m") or ""):
+        return None
+    try:
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=30).stdout
+        ids = [l.split(":")[-1].strip() for l in out.splitlines() if "Unique ID" in l and "GPU[" in l]
+        return "GPU unique id: %s" % ", ".join(ids)
+    except Exception as e:                                   # noqa: BLE001
+        return "GPU unique id: unavailable (%r)" % (e,)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

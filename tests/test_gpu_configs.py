@@ -283,3 +283,35 @@ def test_interference_closed_form_on_gpu(golden, channels):
             for ci in range(3):
                 want = W.interference.interf_power(st, w_tx[pi], w_rx[pi], h[ci])
                 assert np.abs(got[pi, ci] - want).max() < 5e-5 * np.abs(want).max() + 1e-9, (system, pi, ci)
+
+
+@pytest.mark.parametrize("system", ["wtx", "CPW", "wrx", "CPwtx"])
+def test_tx_psd_on_gpu_replays_the_reference(golden, system):
+    """Row f4 on the GPU (wofdm_tx_psd): the reference's own seeded estimate_obr outputs
+    (tests/golden/timefreq.npz, N = 128: PSD estimate, OBR, main-band samples of the optimised, RC and plain
+    CP waveforms) reproduced with the waveform and the averaged periodogram computed by the HIP kernels."""
+    from wofdm_amd import timefreq as T
+    from wofdm_amd import variants as V
+    g = golden("timefreq.npz")
+    n_fft, cp = (int(v) for v in g["cfg"])
+    st = V.make_structure(system, n_fft, cp)
+    w_tx = V.expand_tx_window(st, g[system + "_xt"])
+    dicts = T.estimate_obr(st, w_tx, 200e-9, rng=np.random.RandomState(int(g[system + "_seed"])), gpu=True)
+    for tag, d in zip(("opt", "rc", "cp"), dicts):
+        for key in ("X_est_" + tag, "obr_" + tag, "mf_band_" + tag):
+            ref = g[system + "_" + key]
+            assert np.allclose(d[key], ref, rtol=2e-4, atol=2e-5 * np.abs(g[system + "_X_est_" + tag]).max()), key
+
+
+@pytest.mark.parametrize("system,n_fft,cp", [("WOLA", 256, 32), ("CP", 64, 16), ("wtx", 256, 10)])
+def test_tx_psd_on_gpu_matches_the_host_mirror(system, n_fft, cp):
+    from wofdm_amd import timefreq as T
+    st = W.make_structure(system, n_fft, cp)
+    rs = np.random.RandomState(n_fft + cp)
+    gb = 48 if n_fft >= 128 else 8
+    X = T.draw_symbols(n_fft, rs, no_symbols=100, guard_band=gb)
+    w_tx = W.tx_rc_window(st)
+    ov = st.tail_tx
+    want = T.psd_estimate(T.overlap_and_add(T.tx_symbols(st, X, w_tx, gb), ov), 8 * n_fft)
+    got = T.psd_estimate_gpu(st, X, w_tx, ov, guard_band=gb)
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()

@@ -27,7 +27,7 @@ EXPORTS = (
     "wofdm_plan_launch_injected", "wofdm_plan_dump_frame", "wofdm_plan_info", "wofdm_run",
     "wofdm_run_injected", "wofdm_philox_kat", "wofdm_plan_set_allocation",
     "wofdm_plan_set_tx_mask", "wofdm_plan_status", "wofdm_plan_kernel_id",
-    "wofdm_interference",
+    "wofdm_interference", "wofdm_tx_psd",
 )
 
 
@@ -123,6 +123,7 @@ def load():
     L.wofdm_run_injected.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.wofdm_philox_kat.argtypes = [C.c_int, vp, vp, vp]
     L.wofdm_interference.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp]
+    L.wofdm_tx_psd.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, C.c_int, C.c_int, vp]
     _LIB = L
     return L
 

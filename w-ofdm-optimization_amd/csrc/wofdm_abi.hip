@@ -760,6 +760,52 @@ int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, cons
     return rc;
 }
 
+int wofdm_tx_psd(const wofdm_cfg *cfg, int device, const float *w_tx, const float *X, int no_symbols,
+                 int overlap, float *psd)
+{
+    if (!cfg || !w_tx || !X || !psd) return fail(WOFDM_E_INVALID, "NULL argument");
+    const int N = cfg->n_fft;
+    if (N != 64 && N != 128 && N != 256)
+        return fail(WOFDM_E_UNSUPPORTED, "wofdm_tx_psd is built for n_fft in {64,128,256} (transform length 8 n_fft)");
+    const int P = N + cfg->cp + cfg->cs;
+    if (cfg->cp < 0 || cfg->cs < 0 || cfg->cp > N || cfg->cs > N || overlap < 0 || 2 * overlap > P || no_symbols < 1)
+        return fail(WOFDM_E_INVALID, "bad cp / cs / overlap / no_symbols");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(WOFDM_E_HIP, "device %d not available (%d visible); there is no CPU fallback", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    const int FL = 8 * N, len = overlap + no_symbols * (P - overlap);
+    float *d_w = nullptr, *d_psd = nullptr;
+    float2 *d_X = nullptr, *d_x = nullptr;
+    int rc = WOFDM_OK;
+    do {
+        if (hipMalloc(&d_w, (size_t)P * 4) != hipSuccess || hipMalloc(&d_X, (size_t)no_symbols * N * 8) != hipSuccess ||
+            hipMalloc(&d_x, (size_t)len * 8) != hipSuccess || hipMalloc(&d_psd, (size_t)FL * 4) != hipSuccess) {
+            rc = fail(WOFDM_E_NOMEM, "device allocation failed"); break;
+        }
+        if (hipMemcpy(d_w, w_tx, (size_t)P * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_X, X, (size_t)no_symbols * N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(d_x, 0, (size_t)len * 8) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "upload failed"); break;
+        }
+        hipError_t e = hipErrorInvalidValue;
+        if (N == 64) e = wofdm_psd_launch_n64(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);
+        if (N == 128) e = wofdm_psd_launch_n128(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);
+        if (N == 256) e = wofdm_psd_launch_n256(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);
+        if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(psd, d_psd, (size_t)FL * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(WOFDM_E_HIP, "PSD kernels or copy-back failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (d_w) (void)hipFree(d_w);
+    if (d_X) (void)hipFree(d_X);
+    if (d_x) (void)hipFree(d_x);
+    if (d_psd) (void)hipFree(d_psd);
+    return rc;
+}
+
 int wofdm_philox_kat(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     if (!ctr || !key || !out) return fail(WOFDM_E_INVALID, "NULL argument");

@@ -211,3 +211,10 @@ WOFDM_INTERF_DECL(128);
 WOFDM_INTERF_DECL(256);
 WOFDM_INTERF_DECL(512);
 WOFDM_INTERF_DECL(1024);
+// Tx waveform + averaged periodogram (row f4), N <= 256 (transform length 8 N <= 2048)
+#define WOFDM_PSD_DECL(n)                                                                                         \
+    hipError_t wofdm_psd_launch_n##n(int P, int mu, int rho, int overlap, int no_symbols, const float *wtx,        \
+                                     const float2 *X, float2 *x, int len, float *psd, hipStream_t s)
+WOFDM_PSD_DECL(64);
+WOFDM_PSD_DECL(128);
+WOFDM_PSD_DECL(256);

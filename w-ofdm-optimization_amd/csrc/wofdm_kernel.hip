@@ -2139,6 +2139,136 @@ wofdm_interf_kernel(const wofdm_iparams p, const float *__restrict__ g_wtx, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tx-side spectrum estimate: the transmitted waveform of a long run of symbols
+// and its averaged periodogram,
+//   wOFDMSystem.estimate_obr   python/ofdm_utils/timefreq_simulation.py:216-296 (Tx chain 242-258)
+//   psd_estimate               timefreq_simulation.py:101-123
+// The waveform kernel is phase A of the frame kernel fed with given symbols X[s][n] (any complex values,
+// zeros on unloaded bins): IDFT, CP/CS copy, Tx window, overlap-add of the `overlap` tail samples --
+// one wave per symbol, the overlapping samples by float atomics (two addends: order-independent).
+struct wofdm_wparams {
+    int P, mu, rho, overlap, no_symbols;
+    float2 *x;                         // [overlap + no_symbols * (P - overlap)], zeroed by the host
+};
+template <int N>
+__global__ void __launch_bounds__(1024) wofdm_txwave_kernel(const wofdm_wparams p, const float *__restrict__ g_wtx,
+                                                            const float2 *__restrict__ X)
+{
+    constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
+    constexpr bool FULL = geo<N>::FULL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v2f *tw = reinterpret_cast<v2f *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    v2f *scr = tw + N + (size_t)wv * N;
+    fill_twiddles<N>(tw, tid, 1024);
+    __syncthreads();
+    const int s = blockIdx.x * 16 + wv;
+    if (s >= p.no_symbols) return;
+    v2f v[1][BPL][4];
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[0][q][r] = mk(0.f, 0.f);
+            if (FULL || lane + 64 * q < NQ) v[0][q][r] = ldg2(X + (size_t)s * N + lane + 64 * q + r * NQ);
+        }
+    fft_wave<N, +1, 1>(v, scr, 0, tw, lane);                    // N x[t]
+    const int Bo = p.P - p.overlap;
+    float2 *out = p.x + (size_t)s * Bo;
+    auto put = [&](int i, v2f val) {
+        val = val * (g_wtx[i] * (1.0f / (float)N));
+        if (i < p.overlap || i >= Bo) {                          // shared with a neighbour symbol
+            atomicAdd(&out[i].x, val.x);
+            atomicAdd(&out[i].y, val.y);
+        } else {
+            out[i] = make_float2(val.x, val.y);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < BPL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!(FULL || lane + 64 * q < NQ)) continue;
+            const int t = lane + 64 * q + r * NQ;
+            put(t + p.mu, v[0][q][r]);
+            if (t >= N - p.mu) put(t + p.mu - N, v[0][q][r]);
+            if (t < p.rho) put(t + p.mu + N, v[0][q][r]);
+        }
+}
+
+// Sum over consecutive FL-sample slices of x (the zero-padded remainder included) of |FFT_FL|^2, written
+// fftshift-ed; the caller divides by the reference's slice count.  FL = 2048 runs as two 1024-point
+// transforms of the even and odd samples and one radix-2 combination in registers.
+template <int FL>
+__global__ void __launch_bounds__(512) wofdm_psd_kernel(const float2 *__restrict__ x, int len, int n_slices,
+                                                        float *__restrict__ psd)
+{
+    constexpr int M = FL == 2048 ? 1024 : FL, H = FL / M;        // transform length, transforms per slice
+    constexpr int BPL = geo<M>::BPL, NQ = geo<M>::NQ, WAVES = 8;
+    static_assert(geo<M>::FULL, "at least 256 points");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v2f *tw = reinterpret_cast<v2f *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    v2f *scr = tw + M + (size_t)wv * M;
+    fill_twiddles<M>(tw, tid, WAVES * 64);
+    __syncthreads();
+    float acc[H][BPL][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int q = 0; q < BPL; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[h][q][r] = 0.f;
+    for (int sl = wv; sl < n_slices; sl += WAVES) {
+        v2f e[1][BPL][4], o[1][BPL][4];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            v2f (&dst)[1][BPL][4] = h == 0 ? e : o;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = sl * FL + H * (lane + 64 * q + r * NQ) + h;       // even / odd samples
+                    dst[0][q][r] = idx < len ? ldg2(x + idx) : mk(0.f, 0.f);
+                }
+            fft_wave<M, -1, 1>(dst, scr, 0, tw, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < BPL; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (H == 2) {
+                    const int k = lane + 64 * q + r * NQ;
+                    float sv, cv;
+                    sincospif(-2.0f * (float)k / (float)FL, &sv, &cv);
+                    const v2f wo = cmul(o[0][q][r], mk(cv, sv));
+                    const v2f a = e[0][q][r] + wo, b = e[0][q][r] - wo;
+                    acc[0][q][r] += a.x * a.x + a.y * a.y;
+                    acc[1][q][r] += b.x * b.x + b.y * b.y;
+                } else {
+                    acc[0][q][r] += e[0][q][r].x * e[0][q][r].x + e[0][q][r].y * e[0][q][r].y;
+                }
+            }
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(tw + M);                 // [WAVES][FL] over the scratch rows
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int q = 0; q < BPL; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv * FL + h * M + lane + 64 * q + r * NQ] = acc[h][q][r];
+    __syncthreads();
+    for (int k = tid; k < FL; k += WAVES * 64) {
+        float t = 0.f;
+        for (int w = 0; w < WAVES; ++w) t += red[w * FL + k];
+        psd[(k + FL / 2) & (FL - 1)] = t;
+    }
+}
+
 __global__ void philox_kat_kernel(const uint32_t *ck, uint32_t *out)
 {
     if (threadIdx.x == 0) {
@@ -2233,6 +2363,24 @@ hipError_t WOFDM_CAT(wofdm_interf_launch_n, WOFDM_TU_N)(int jobs, int P, int B, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wofdm_interf_kernel<N>, dim3(jobs), dim3(W * 64), lds, s, ip, wtx, wrx, h);
+    return hipGetLastError();
+}
+#endif
+
+#if WOFDM_TU_K == 2 && WOFDM_TU_N <= 256
+// Tx waveform + periodogram (row f4), per DFT length, in the k = 2 translation units
+hipError_t WOFDM_CAT(wofdm_psd_launch_n, WOFDM_TU_N)(int P, int mu, int rho, int overlap, int no_symbols, const float *wtx,
+                                                     const float2 *X, float2 *x, int len, float *psd, hipStream_t s)
+{
+    constexpr int N = WOFDM_TU_N, FL = 8 * N, M = FL == 2048 ? 1024 : FL;
+    wofdm_wparams wp;
+    wp.P = P; wp.mu = mu; wp.rho = rho; wp.overlap = overlap; wp.no_symbols = no_symbols; wp.x = x;
+    const size_t lds_a = 8 * (size_t)N * 17, lds_b = 8 * (size_t)M * 9;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wofdm_psd_kernel<FL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wofdm_txwave_kernel<N>, dim3((no_symbols + 15) / 16), dim3(1024), lds_a, s, wp, wtx, X);
+    hipLaunchKernelGGL(wofdm_psd_kernel<FL>, dim3(1), dim3(512), lds_b, s, (const float2 *)x, len, (len + FL - 1) / FL, psd);
     return hipGetLastError();
 }
 #endif

@@ -66,6 +66,27 @@ def psd_estimate(x, fft_len):
     return np.fft.fftshift(acc) / (n_full + 1)
 
 
+def psd_estimate_gpu(st, X, w_tx, overlap, guard_band=GUARD_BAND, device=0):
+    """``psd_estimate(overlap_and_add(tx_symbols(st, X, w_tx), overlap), 8 N)`` on the GPU
+    (``wofdm_tx_psd``: the frame kernel's Tx half on the given symbols + the averaged periodogram).
+    X: [N - 2 gb, no_symbols] like ``draw_symbols``.  No CPU fallback; N in {64, 128, 256}."""
+    import ctypes as C
+    from . import _lib
+    from .simulation import make_cfg
+    n = st.n_fft
+    X = np.asarray(X)
+    grid = np.zeros((X.shape[1], n), dtype=np.complex64)
+    grid[:, allocation_index(n, guard_band)] = X.T
+    w = _lib.f32(np.asarray(w_tx).reshape(-1), (st.sym_len,))
+    cfg = make_cfg(st, 4, 16, 1, 1, 1, 1)
+    out = np.zeros(8 * n, dtype=np.float32)
+    gf = _lib.c64_as_f32(grid)
+    _lib.check(_lib.load().wofdm_tx_psd(C.byref(cfg), int(device), w.ctypes.data, gf.ctypes.data,
+                                        int(X.shape[1]), int(overlap), out.ctypes.data))
+    length = overlap + X.shape[1] * (st.sym_len - overlap)
+    return out.astype(np.float64) / (length // (8 * n) + 1)
+
+
 def analytical_psd(st, w_tx, sampling_period, guard_band=GUARD_BAND, fft_len=None):
     """(S_opt, S_rc, S_cp) of lines 155-214 for the Tx window ``w_tx`` (vector, length P)."""
     from scipy.signal import firwin
@@ -92,9 +113,9 @@ def analytical_psd(st, w_tx, sampling_period, guard_band=GUARD_BAND, fft_len=Non
             spectrum(np.ones(st.sym_len), n + cp, (n + cp, cp, 0.0)))
 
 
-def estimate_obr(st, w_tx, samp_period=200e-9, X=None, rng=None):
+def estimate_obr(st, w_tx, samp_period=200e-9, X=None, rng=None, gpu=False):
     """``wOFDMSystem.estimate_obr`` (lines 216-296): three dicts (optimised window, RC window,
-    plain CP-OFDM) with the reference's keys."""
+    plain CP-OFDM) with the reference's keys.  gpu=True: waveform and periodogram by ``wofdm_tx_psd``."""
     n = st.n_fft
     fft_len = 8 * n
     X = draw_symbols(n, rng) if X is None else np.asarray(X)
@@ -108,8 +129,9 @@ def estimate_obr(st, w_tx, samp_period=200e-9, X=None, rng=None):
     gb = int(interp * GUARD_BAND)
     S = analytical_psd(st, w_tx, samp_period, GUARD_BAND, fft_len)
     out = []
+    wins = {"opt": (w_tx, overlap), "rc": (V.tx_rc_window(st), overlap), "cp": (np.ones(st.sym_len), 0)}
     for tag, x, s in (("opt", x_opt, S[0]), ("rc", x_rc, S[1]), ("cp", x_cp, S[2])):
-        est = psd_estimate(x, fft_len)
+        est = psd_estimate_gpu(st, X, *wins[tag]) if gpu else psd_estimate(x, fft_len)
         out.append({"X_est_" + tag: est, "S_" + tag: s, "f_axis": f_axis,
                     "obr_" + tag: np.mean(np.hstack((est[:gb], est[-gb:]))),
                     "mf_band_" + tag: np.hstack((est[gb:fft_len // 2],
