@@ -55,6 +55,10 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
+#ifndef WOFDM_ENTRY_ACQUIRE
+#define WOFDM_ENTRY_ACQUIRE 1
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -436,6 +440,71 @@ __device__ __forceinline__ void fft_big(v2f (&v)[1][geo<N>::BPL][4], v2f *fb, co
     wave_sync();
 }
 
+// The same 1024-point transform with a 512-entry (4 KB) exchange buffer: both exchanges run in two
+// halves.  Exchange 1: the 16 stage-1 outputs of lane l go to entries 16 l ... 16 l + 15, so lanes 0..31
+// fill entries [0, 512) and every lane fetches its r = 0, 1 operands (entries j, j + 256), then lanes
+// 32..63 fill the buffer again for r = 2, 3.  Exchange 2: butterfly j = lane + 64 q writes block
+// floor(j / 16) = floor(lane / 16) + 4 q of 64 entries, and the last stage reads one entry per block:
+// q = 0, 1 (blocks 0..7, inputs t = 0..7) first, q = 2, 3 second -- no extra store there.  Lets all 16
+// waves of a workgroup run the 1024-point Tx-mask transforms at once (16 x 4 KB instead of 8 x 8 KB).
+template <int DIR>
+__device__ __forceinline__ void fft_1024_half(v2f (&v)[1][4][4], v2f *fb, const v2f *tw, int lane)
+{
+    constexpr int T2 = 48;
+    dft_lane<1024, DIR>(v[0]);
+    v2f u4[4][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        if ((lane >> 5) == hf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fb[swz<16>(16 * (lane & 31) + r + 4 * q)] = v[0][q][r];
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) u4[q][2 * hf + rr] = fb[swz<16>(lane + 64 * q + 256 * rr)];
+        wave_sync();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = (lane + 64 * q) & 15;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) u4[q][r] = twid<DIR>(u4[q][r], tw[3 * k + r - 1]);
+        radix4<DIR>(u4[q]);
+    }
+    v2f x[4][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int k = lane & 15;                      // (lane + 64 q) & 15
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[((lane - k) << 2) + 256 * qq + k + 16 * r] = u4[2 * hf + qq][r];
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * hf + rr, t = q + 4 * r;
+                x[q][r] = fb[lane + 64 * (t - 8 * hf)];
+                if (t > 0) x[q][r] = twid<DIR>(x[q][r], tw[T2 + 15 * lane + t - 1]);
+            }
+        wave_sync();
+    }
+    dft_lane<1024, DIR>(x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = q + 4 * r;
+            v[0][q][r] = x[u >> 2][u & 3];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // N = 256, four symbols per wave ("quarter-wave" layout): 16 lanes own one symbol, lane l of the
 // quarter holds elements l + 16 t, t = q + 4 r.  256 = 16.16: both stages are in-register 16-point
@@ -752,6 +821,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool RELAUNDER = N >= 1024 || (N >= 512 && VAR >= 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+#if WOFDM_ENTRY_ACQUIRE
+    // System-scope acquire before the first read of the plan's constants (buffer_inv sc0 sc1): they were
+    // written by hipMemcpy into device memory that an earlier, destroyed plan may have used for OTHER
+    // constants, and lines of those can still sit in this XCD's L2 (see launch() in wofdm_abi.hip).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
     const int tid = threadIdx.x, lane0 = tid & 63;
     // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1103,32 +1178,44 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const bool lastsym = s == S - 1;
             const int DtH = lastsym ? B : 2 * tail_off + s * TS - B - (8 + 2 * B * s);
             const int DtL = lastsym ? B + VT : DtH + S * TS;
+            const bool body_tail = rho < gq[WOFDM_G_BETA];
+            // per-lane bases once, element offsets as instruction immediates (see the quarter-wave form)
+            uint32_t *pH = hrow + (lane + mu), *pL = pH + B;
+            const float *pW = wtx + (lane + mu);
+            uint32_t *pHp = pH - N, *pLp = pL - N;
+            const float *pWp = pW - N;
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
-                const int j = lane + 64 * q;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int t = j + r * NQ;
+                    const int e = 64 * q + r * NQ, t = lane + e;
                     const v2f x = v[0][q][r];
-                    auto put_plain = [&](int i) {
-                        uint32_t hi, lo;
-                        split_h(x * wtx[i], hi, lo);
-                        hrow[i] = hi;
-                        hrow[i + B] = lo;
-                    };
+                    uint32_t hi, lo;
                     auto put_tail = [&](int i) {
-                        uint32_t hi, lo;
                         split_h(x * wtx[i], hi, lo);
                         const bool tl = i >= B;
                         hrow[i + (tl ? DtH : 0)] = hi;
                         hrow[i + (tl ? DtL : B)] = lo;
                     };
-                    if (rho < gq[WOFDM_G_BETA]) put_tail(t + mu);
-                    else put_plain(t + mu);
-                    if (63 + 64 * q + r * NQ >= N - L::CPCS_MAX)
-                        if (t >= N - mu) put_plain(t + mu - N);
-                    if (64 * q + r * NQ < L::CPCS_MAX)
-                        if (t < rho) put_tail(t + mu + N);
+                    if (body_tail) {
+                        put_tail(t + mu);
+                    } else {
+                        split_h(x * pW[e], hi, lo);
+                        pH[e] = hi;
+                        pL[e] = lo;
+                    }
+                    if (63 + e >= N - L::CPCS_MAX)
+                        if (e + 63 >= N - mu) {
+                            if (t >= N - mu) {
+                                split_h(x * pWp[e], hi, lo);
+                                pHp[e] = hi;
+                                pLp[e] = lo;
+                            }
+                        }
+                    if (e < L::CPCS_MAX)
+                        if (e < rho) {
+                            if (t < rho) put_tail(t + mu + N);
+                        }
                 }
             }
         } else if constexpr (FIRQ) {
@@ -1216,38 +1303,34 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // dft_rc_filt as fast convolution.  y[n] = sum_m g[(n - m) mod (2P-1)] x[m], n < 2P-1,
             // is the linear convolution of x with gt[t] = g[(t - (P-1)) mod (2P-1)], t < 3P-2, read
             // at j = n + P - 1; an MF-point circular convolution gives exactly those samples when
-            // 3P - 2 <= MF (only j < P-1 alias).  g_tmask holds FFT_MF(gt) / MF.  The MF-point
-            // scratch rows do not fit for all 16 waves at once: the waves take turns, MF_SLOTS at a time.
+            // 3P - 2 <= MF (only j < P-1 alias).  g_tmask holds FFT_MF(gt) / MF.  All waves transform at
+            // once, each through its own half-size exchange buffer (fft_1024_half).
             constexpr int MF = maskfft_geo::MF, MQ = MF / 4, MBPL = MQ / 64, SLOTS = maskfft_geo::SLOTS;
             const int P = gq[WOFDM_G_P];
             const int s = s0;
             v2f *fb = fbw;
             const bool last = s == S - 1;
             const v2f *xt = last ? fb + B : tailb + s * TS;
-            v2f *scr = mscr + (wv % SLOTS) * MF;
+            static_assert(MF == 1024 && MBPL == 4 && SLOTS == 8, "fft_1024_half: 16 half-size exchange rows");
+            v2f *scr = mscr + wv * (MF / 2);          // every wave its own 4 KB exchange buffer
             v2f y[1][MBPL][4];
             wave_sync();
-            for (int round = 0; round * SLOTS < S; ++round) {
-                if (wv / SLOTS == round) {
 #pragma unroll
-                    for (int q = 0; q < MBPL; ++q)
+            for (int q = 0; q < MBPL; ++q)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = lane + 64 * q + r * MQ;
-                            v2f xm = mk(0.f, 0.f);
-                            if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
-                            y[0][q][r] = xm;
-                        }
-                    fft_wave<MF, -1, 1>(y, scr, 0, mtw, lane);
-#pragma unroll
-                    for (int q = 0; q < MBPL; ++q)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            y[0][q][r] = cmul(y[0][q][r], ldg2(g_tmask + lane + 64 * q + r * MQ));
-                    fft_wave<MF, +1, 1>(y, scr, 0, mtw, lane);
+                for (int r = 0; r < 4; ++r) {
+                    const int m = lane + 64 * q + r * MQ;
+                    v2f xm = mk(0.f, 0.f);
+                    if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
+                    y[0][q][r] = xm;
                 }
-                __syncthreads();
-            }
+            fft_1024_half<-1>(y, scr, mtw, lane);
+#pragma unroll
+            for (int q = 0; q < MBPL; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    y[0][q][r] = cmul(y[0][q][r], ldg2(g_tmask + lane + 64 * q + r * MQ));
+            fft_1024_half<+1>(y, scr, mtw, lane);
             // own row <- y[0..P): element j = n + P - 1
 #pragma unroll
             for (int q = 0; q < MBPL; ++q)
@@ -1827,23 +1910,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
         const int h2 = delta >> 1;
-        // (two passes: all main-tap loads in flight together, free of branches; the folded samples --
-        // at most tail_rx of the N per symbol -- only where there is an Rx tail at all)
-#pragma unroll
-        for (int u = 0; u < VS; ++u) {
-            const v2f *fb = row(sym_of(u) - s0);
-#pragma unroll
-            for (int q = 0; q < VB; ++q) {
-                if (owns(q)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
-                        v[u][q][r] = fb[gam + m0] * wrx[m0];
-                    }
-                }
-            }
-        }
-        if (delta > 0) {
+        // Production kernels leave the circular shift out: z'[t] = z[t - kappa - delta/2] turns into the
+        // factor e^{-2 pi i (kappa + delta/2) n / N} on subcarrier n of EVERY symbol of the frame, the
+        // pilot included, and the one-tap equaliser X^[s] = Y[s] X0 / Y0 (m:266-268) divides it out again.
+        // Without it the lane's elements sit at fixed offsets from one per-lane base (addresses as
+        // instruction immediates), and only the first tail_rx <= 64 samples of a symbol can have a folded
+        // partner.  The instrumented kernels keep the shift: their Y is compared with the reference's.
+        if constexpr (DUMP) {
+            // (two passes: all main-tap loads in flight together, free of branches; the folded samples
+            // only where there is an Rx tail at all)
 #pragma unroll
             for (int u = 0; u < VS; ++u) {
                 const v2f *fb = row(sym_of(u) - s0);
@@ -1853,9 +1928,65 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
-                            if (m0 < delta) {
-                                const float w2 = wrx[m0 + N];
-                                v[u][q][r] = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], v[u][q][r]);
+                            v[u][q][r] = fb[gam + m0] * wrx[m0];
+                        }
+                    }
+                }
+            }
+            if (delta > 0) {
+#pragma unroll
+                for (int u = 0; u < VS; ++u) {
+                    const v2f *fb = row(sym_of(u) - s0);
+#pragma unroll
+                    for (int q = 0; q < VB; ++q) {
+                        if (owns(q)) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
+                                if (m0 < delta) {
+                                    const float w2 = wrx[m0 + N];
+                                    v[u][q][r] = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], v[u][q][r]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            (void)kap;
+            const int l0 = QW ? llq : lane;                      // the lane's first element of a symbol
+#pragma unroll
+            for (int u = 0; u < VS; ++u) {
+                const v2f *fy = row(sym_of(u) - s0) + (gam + l0);
+                const float *wr = wrx + l0;
+#pragma unroll
+                for (int q = 0; q < VB; ++q) {
+                    if (owns(q)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = QW ? 16 * (q + 4 * r) : 64 * q + r * NQ;      // sub_of(q, r) - l0
+                            v[u][q][r] = fy[e] * wr[e];
+                        }
+                    }
+                }
+            }
+            if (delta > 0) {
+#pragma unroll
+                for (int u = 0; u < VS; ++u) {
+                    const v2f *fy = row(sym_of(u) - s0) + (gam + l0);
+                    const float *wr = wrx + l0;
+#pragma unroll
+                    for (int q = 0; q < VB; ++q) {
+                        if (owns(q)) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int e = QW ? 16 * (q + 4 * r) : 64 * q + r * NQ;
+                                if (e < L::TAILRX_MAX) {                 // compile time: sample e + l0 < tail_rx?
+                                    if (e + l0 < delta) {
+                                        const float w2 = wr[e + N];
+                                        v[u][q][r] = __builtin_elementwise_fma(mk(w2, w2), fy[e + N], v[u][q][r]);
+                                    }
+                                }
                             }
                         }
                     }
