@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle, on the same seeded
 inputs.  Integer work (Philox words, labels, bit totals) must be bit-exact; floating-point
 stages are fp32 on the GPU vs fp64 in the oracle, tolerance written per check."""
+import os
+
 import numpy as np
 import pytest
 
@@ -398,6 +400,9 @@ def _poison():
     path = os.path.join(os.path.dirname(__file__), "..", "w-ofdm-optimization_amd", "libwofdm_poison.so")
     lib = ctypes.CDLL(path)
     lib.scratch_poison.argtypes = [ctypes.c_uint32]
+    lib.lds_poison.argtypes = [ctypes.c_uint32]
+    lib.reg_poison.argtypes = [ctypes.c_uint32]
+    lib.lds_peek.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
     return lib
 
 
@@ -465,6 +470,8 @@ def test_every_spilling_production_kernel(channels, monkeypatch, n_fft, k, layou
         # every scratch slot of the queue filled with a NaN pattern: a spill slot reloaded without having
         # been written in this launch cannot pass for the value an earlier launch left there
         assert _poison().scratch_poison(0x7FC0DEAD) == 0
+        # ... and the same for every CU's LDS and every SIMD's vector registers
+        assert _poison().lds_poison(0xFFFFFFFF) == 0 and _poison().reg_poison(0xFFFFFFFF) == 0
         if inject:
             # the oracle's own Philox draws, handed over as injected data
             nl = O.noise_len(osys)
@@ -521,3 +528,48 @@ with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.comple
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WOFDM_LIB=lib),
                          capture_output=True, text=True, timeout=300)
     assert "CODE -3" in out.stdout, (out.stdout, out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,k,inject,var", [(1024, 6, 1, 0), (1024, 6, 0, 0), (512, 4, 0, 0), (256, 4, 0, 0), (256, 4, 1, 1)])
+def test_first_launch_in_a_fresh_process(n_fft, k, inject, var):
+    """A kernel's FIRST launch in a process (cold instruction cache and TLB) equals its later launches, frame by
+    frame.  Round 2: an MFMA chain of the injected N = 1024 / 64-QAM kernel straddled a page, and a few frames
+    of every first launch came out wrong (tests/test_code_layout.py is the static check)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cold_launch_probe.py"), str(n_fft), str(k), str(inject), str(var)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.split("\n") if "frames differing" in l][-1]
+    assert "launch 0   0, launch 1   0, launch 2   0" in line, line
+
+
+def test_lds_poison_tool_works():
+    """The helper's own check: a fresh LDS allocation shows what the previous workgroup on the CU left there."""
+    lib = _poison()
+    hits = np.zeros(512, np.uint32)
+    assert lib.lds_poison(0xC0FFEE11) == 0
+    assert lib.lds_peek(0xC0FFEE11, hits.ctypes.data, 512) == 0
+    assert (hits == 160 * 1024 // 4).all()
+
+
+@pytest.mark.parametrize("system,n_fft,k,S", [("wtx", 256, 4, 16), ("CPW", 256, 6, 16), ("WOLA", 256, 2, 12), ("WOLA", 256, 4, 6),
+                                               ("WOLA", 512, 4, 16), ("CPW", 512, 6, 7), ("WOLA", 1024, 6, 16), ("CPW", 1024, 2, 13),
+                                               ("wtx", 128, 4, 16), ("WOLA", 64, 2, 16)])
+def test_no_kernel_reads_what_an_earlier_kernel_left_on_chip(channels, system, n_fft, k, S):
+    """LDS words, vector registers and scratch slots all survive from one kernel to the next: a frame kernel
+    that read any of them before writing it would give the same answer launch after launch of ONE plan and a
+    different one after a different kernel.  Every on-chip store is filled with NaN / zero / 1.0 patterns
+    before a launch; the counters must not move."""
+    st = W.make_structure(system, n_fft, 32 if n_fft >= 256 else 16)
+    cfg = W.make_cfg(st, k, S, 21, 2, 3, 1, seed=8)
+    F = max(4, int(1e6 / ((S - 1) * n_fft * k)))
+    lib = _poison()
+    with W.Plan(cfg, W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32),
+                channels[11:13].astype(np.complex64), np.array([5.0, 15.0, 25.0], np.float32)) as plan:
+        ref = plan.run(3, F)
+        for pat in (0xFFFFFFFF, 0x00000000, 0x3C003C00, 0x7BFF7BFF):
+            assert lib.lds_poison(pat) == 0 and lib.reg_poison(pat) == 0 and lib.scratch_poison(pat) == 0
+            assert np.array_equal(plan.run(3, F), ref), hex(pat)

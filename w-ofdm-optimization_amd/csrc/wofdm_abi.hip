@@ -103,8 +103,10 @@ struct wofdm_plan {
     // Kernels with register spills (ScratchSize > 0): the first launch on a stream is preceded by a
     // one-frame launch of the same kernel into a dummy counter (see launch()).
     size_t scratch_bytes[4] = {0, 0, 0, 0};
-    std::vector<std::pair<hipStream_t, int>> warmed;   // (stream, mode) pairs already warmed
-    unsigned long long *d_warm = nullptr;
+#ifdef WOFDM_AUDIT
+    uint32_t *audit = nullptr;
+    uint32_t audit_items = 0;
+#endif
     int occ = 1, cus = 1, spw = 1;     // spw: layout id of the kernels in use (wofdm_spw)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -144,7 +146,6 @@ int configure(wofdm_plan *pl)
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn[m])));
         pl->scratch_bytes[m] = fa.localSizeBytes;
     }
-    pl->warmed.clear();
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw), lds));
@@ -188,30 +189,17 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     kp.tx_scale = pl->base.tx_scale;
     kp.dump_unscale_tx = pl->base.dump_unscale_tx;
     kp.dump_unscale_rx = pl->base.dump_unscale_rx;
-    // First launch of a plan on a stream: preceded by a throw-away one-frame launch of the same kernel
-    // with the same inputs into a dummy counter.  Round 2 found the counters of a plan's FIRST launch off
-    // by tens of bit errors (a few frames out of thousands) in about a quarter of fresh processes, on
-    // different GPUs, so far only at N = 1024; every later launch of the same plan is bit-identical to
-    // every other.  Ruled out: register-spill slots read before written (scratch poisoned in the tests;
-    // the N = 1024 kernels are scratch-free now and still did it), the parked-noise round trip through
-    // HBM (store -> vmcnt(0) -> load made no difference; buffer pre-touched), one bad device.  Not found:
-    // the cause.  WOFDM_NO_WARMUP=1 switches the extra launch off.
-    const char *nw = std::getenv("WOFDM_NO_WARMUP");
-    if (mode < WOFDM_MODE_DUMP_GEN && !(nw && nw[0] == '1')) {
-        bool seen = false;
-        for (auto &w : pl->warmed) seen = seen || (w.first == stream && w.second == mode);
-        if (!seen) {
-            if (!pl->d_warm) HIP_TRY(hipMalloc(&pl->d_warm, 4 * sizeof(unsigned long long)));
-            wofdm_kparams wp = kp;
-            wp.counts = pl->d_warm; wp.n_cells = 1; wp.first_cell = kp.inject_base_cell;
-            wp.frames_per_cell = 1; wp.items_q = 1; wp.items_r = 0;
-            void *wargs[] = {&wp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
-                             &pl->d_fira};
-            HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3(1u),
-                                    dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), wargs, kp.lds_bytes, stream));
-            pl->warmed.emplace_back(stream, mode);
-        }
+#ifdef WOFDM_AUDIT
+    kp.audit = pl->audit; kp.audit_items = pl->audit_items;
+#endif
+#ifdef WOFDM_DELAY
+    {
+        const char *dp = std::getenv("WOFDM_DELAY_POINT"), *dw = std::getenv("WOFDM_DELAY_WAVES"), *dn = std::getenv("WOFDM_DELAY_LEN");
+        kp.delay_point = dp ? (uint32_t)std::strtoul(dp, nullptr, 0) : 0;
+        kp.delay_waves = dw ? (uint32_t)std::strtoul(dw, nullptr, 0) : 0;
+        kp.delay_len = dn ? (uint32_t)std::strtoul(dn, nullptr, 0) : 8;
     }
+#endif
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
                     &pl->d_fira};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
@@ -398,7 +386,6 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
     if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->d_fira) (void)hipFree(pl->d_fira);
-    if (pl->d_warm) (void)hipFree(pl->d_warm);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
@@ -523,6 +510,15 @@ int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
     return WOFDM_OK;
 }
 
+#ifdef WOFDM_AUDIT
+// developer build only: device buffer of [grid][items][16][8] words for the per-frame records
+extern "C" int wofdm_plan_set_audit(wofdm_plan *pl, void *dev, uint32_t items)
+{
+    if (!pl) return WOFDM_E_INVALID;
+    pl->audit = static_cast<uint32_t *>(dev); pl->audit_items = items;
+    return WOFDM_OK;
+}
+#endif
 int wofdm_plan_kernel_id(wofdm_plan *pl, int32_t id[2])
 {
     if (!pl || !id) return fail(WOFDM_E_INVALID, "NULL argument");

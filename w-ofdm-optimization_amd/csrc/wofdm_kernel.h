@@ -65,6 +65,16 @@ struct wofdm_kparams {
     // powers, the equaliser divides by the pilot), so only the stage dumps undo it.
     float tx_scale, dump_unscale_tx, dump_unscale_rx;
     wofdm_kdump dump;
+#ifdef WOFDM_DELAY
+    // developer build (tools/delay_probe.py): the waves of delay_waves sleep delay_len x 4 us at point delay_point
+    uint32_t delay_point, delay_waves, delay_len;
+#endif
+#ifdef WOFDM_AUDIT
+    // developer build (tools/audit_suite.py): per (workgroup, frame, wave) record of 8 words -- bit errors,
+    // symbol errors, noise gain, Ps, Pn, HW_ID, XCC_ID, clock -- for the first audit_items frames of a workgroup
+    uint32_t *audit;
+    uint32_t audit_items;
+#endif
 };
 
 // DFT lengths from which the generated unit noise is parked in HBM scratch between the FIR and

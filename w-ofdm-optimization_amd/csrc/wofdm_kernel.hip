@@ -55,10 +55,6 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
-#ifndef WOFDM_ENTRY_ACQUIRE
-#define WOFDM_ENTRY_ACQUIRE 1
-#endif
-
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -80,6 +76,29 @@ namespace {
 #else
 // (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
+#endif
+
+#define WOFDM_STR_(x) #x
+#define WOFDM_STR(x) WOFDM_STR_(x)
+// The FIR's chain of six dependent in-place MFMAs (fir_mma) starts on a 64-byte boundary, so that the whole
+// block -- 56 bytes -- sits in ONE instruction-cache line and one page: an instruction fetch that stalls in
+// the middle of the chain (the chain of one kernel straddled a 4 KB page, whose translation is not cached on
+// a kernel's first launch in a process) left wrong sums in a few frames of that launch.  DESIGN.md section 4;
+// -DWOFDM_MMA_ALIGN=0 rebuilds the unaligned code for tools/cold_launch_probe.py.
+#ifndef WOFDM_MMA_ALIGN
+#define WOFDM_MMA_ALIGN 6
+#endif
+
+// Developer build (-DWOFDM_DELAY, tools/delay_probe.py): chosen waves sleep at a chosen point of the frame,
+// so that a hole in the wave-to-wave synchronisation shows on every launch instead of once in a cold process.
+#ifdef WOFDM_DELAY
+#define DELAY_AT(pt)                                                                           \
+    do {                                                                                       \
+        if (p.delay_point == (pt) && ((p.delay_waves >> wv) & 1u))                             \
+            for (uint32_t d_ = 0; d_ < p.delay_len; ++d_) __builtin_amdgcn_s_sleep(127);       \
+    } while (0)
+#else
+#define DELAY_AT(pt) do { } while (0)
 #endif
 
 // Complex samples are 2-wide float vectors: gfx950 issues one wave64 VALU instruction per
@@ -821,12 +840,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool RELAUNDER = N >= 1024 || (N >= 512 && VAR >= 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-#if WOFDM_ENTRY_ACQUIRE
-    // System-scope acquire before the first read of the plan's constants (buffer_inv sc0 sc1): they were
-    // written by hipMemcpy into device memory that an earlier, destroyed plan may have used for OTHER
-    // constants, and lines of those can still sit in this XCD's L2 (see launch() in wofdm_abi.hip).
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-#endif
     const int tid = threadIdx.x, lane0 = tid & 63;
     // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -868,6 +881,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     uint32_t *tH = reinterpret_cast<uint32_t *>(tailb), *tL = tH + gq[WOFDM_G_S] * gq[WOFDM_G_BETA]; \
     (void)tH; (void)tL; (void)tail_off
 
+    DELAY_AT(11);
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     if (tid < 32) flags[tid] = 0;
     int iter = 0;                                  // frames this workgroup has started
@@ -899,6 +913,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *mscr = mtw + maskfft_geo::MF;
     if constexpr (TXFFT) fill_twiddles<maskfft_geo::MF>(mtw, tid, (int)blockDim.x);
     __syncthreads();
+    DELAY_AT(12);
 
     // QAM constants (qammod/qamdemod Gray, unit average power; m:248-249, 269-270)
     constexpr int k = K, half = K >> 1, m1 = (1 << half) - 1;
@@ -999,6 +1014,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const uint32_t f_lo = (uint32_t)frame, f_hi = (uint32_t)(frame >> 32);
         const size_t inj = ((size_t)(cell - p.inject_base_cell) * F + fidx);
         ++nfr;
+        DELAY_AT(1);
+#ifdef WOFDM_AUDIT
+        float aud_g = 0.f, aud_ps = 0.f, aud_pn = 0.f;    // developer build: per-frame record (tools/audit_suite.py)
+#endif
 
         v2f v[VS][VB][4];
         uint32_t lab[VS][VB];
@@ -1422,6 +1441,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         }
+        DELAY_AT(2);
         STAMP(0);
         if constexpr (RELAX) {
             // ---- "barrier" 1: publish "my symbols are written"; phase B waits for the
@@ -1433,6 +1453,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             __syncthreads();                                                 // ---- barrier 1
         }
         STAMP(1);
+        DELAY_AT(3);
 
         // ------------------------------------------------------------ B: overlap-add, noise, FIR
         // (large DFTs: the lane id is made opaque again per phase, or per-lane index vectors of one
@@ -1589,7 +1610,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // in front, the trailing one the result's latency and the operand reads of the last MFMA.
         auto fir_mma = [&](const bops &o) -> f4 {
             f4 d;
-            asm volatile("s_nop 1\n\t"
+            asm volatile(".p2align " WOFDM_STR(WOFDM_MMA_ALIGN) "\n\t"
+                         "s_nop 1\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %1, %5, 0\n\t"        // h_lo x_hi
                          "v_mfma_f32_16x16x32_f16 %0, %2, %6, %0\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %3, %7, %0\n\t"       // h_hi x_lo
@@ -1655,8 +1677,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         };
+        DELAY_AT(4);
         if (all_full) tiles(std::true_type{});
         else tiles(std::false_type{});
+        DELAY_AT(5);
         const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
         if (tail_total > 0 && wv == 0) {
             // the trailing samples of the frame (they only feed the power sums): one more tile, by
@@ -1839,9 +1863,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         }
+        DELAY_AT(6);
         STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
         STAMP(3);
+        DELAY_AT(7);
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
@@ -1861,6 +1887,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         float Ps = 0.f, Pn = 0.f;
         for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
+#ifdef WOFDM_AUDIT
+        aud_g = g; aud_ps = Ps; aud_pn = Pn;
+#endif
         if constexpr (FIRM) {
             // r = c + g n (m:292-293) as two-sample rows into the wave's private rows.  Quarter-wave
             // layouts: samples [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
@@ -2063,6 +2092,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         }
+        DELAY_AT(8);
         STAMP(4);
         if constexpr (RELAX) {
             if (wv != 0) wait_flag(&flags[16], iter, &flags[20]);                        // ---- "barrier" 3
@@ -2070,6 +2100,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             __syncthreads();                                                 // ---- barrier 3
         }
         STAMP(5);
+        DELAY_AT(9);
 
         // ------------------------------------------------------------ D: equalise, demap, count
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
@@ -2127,6 +2158,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if constexpr (SCALAR_ACC) {
             bit_err += wave_sum_u(be_f);
             sym_err += wave_sum_u(se_f);
+#ifdef WOFDM_AUDIT
+            if (p.audit && (uint32_t)(iter - 1) < p.audit_items) {
+                const unsigned ab = wave_sum_u(be_f), as = wave_sum_u(se_f);
+                if (lane == 0) {
+                    uint32_t *a = p.audit + (((size_t)blockIdx.x * p.audit_items + (uint32_t)(iter - 1)) * 16 + wv) * 8;
+                    a[0] = ab; a[1] = as; a[2] = __float_as_uint(aud_g); a[3] = __float_as_uint(aud_ps);
+                    a[4] = __float_as_uint(aud_pn); a[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+                    a[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); a[7] = (uint32_t)__builtin_amdgcn_s_memtime();
+                }
+            }
+#endif
         }
         STAMP(6);
         if (++fidx == F) { fidx = 0; next_cell(); }
