@@ -736,8 +736,13 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 // of the workgroup).  Bounded: a wave never hangs the GPU on a protocol error, it falls through.
 // A wave that gives up leaves a mark in LDS (gave_up), turned into bit 0 of the plan's status word
 // when the workgroup retires -- the only trace of this in the frame loop is the loop's own counter.
-__device__ __forceinline__ void wait_flag(const volatile int *flag, int target, volatile int *gave_up)
+// (the flag words are addressed as LDS, not through the generic address space: volatile accesses through a
+// generic pointer come out as flat_load / flat_store, which take the vector-memory path to the LDS and back)
+typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+typedef volatile __attribute__((address_space(3))) int lds_vint;
+__device__ __forceinline__ void wait_flag(const volatile int *flag_, int target, volatile int *gave_up)
 {
+    lds_cvint *flag = (lds_cvint *)flag_;
     int budget = 1 << 22;
     while (__builtin_amdgcn_readfirstlane(*flag) < target) {
         if (__builtin_expect(--budget == 0, 0)) {
@@ -751,7 +756,7 @@ __device__ __forceinline__ void wait_flag(const volatile int *flag, int target, 
 __device__ __forceinline__ void post_flag(volatile int *flag, int value, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *flag = value;
+    if (lane == 0) *(lds_vint *)flag = value;
 }
 
 __device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
