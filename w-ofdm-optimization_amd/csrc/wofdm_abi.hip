@@ -100,9 +100,6 @@ struct wofdm_plan {
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
     uint4 *d_fira = nullptr;           // [n_ch][4][64] Toeplitz operands of the matrix-pipe FIR (MFMA A layout)
     float firm_sx = 1.f, firm_sh = 1.f; // powers of two carried by the f16 samples / f16 taps there
-    // Kernels with register spills (ScratchSize > 0): the first launch on a stream is preceded by a
-    // one-frame launch of the same kernel into a dummy counter (see launch()).
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
 #ifdef WOFDM_AUDIT
     uint32_t *audit = nullptr;
     uint32_t audit_items = 0;
@@ -142,9 +139,6 @@ int configure(wofdm_plan *pl)
                         var, masked ? " (the Tx mask needs n_fft <= 512)" : "");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn[m]),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn[m])));
-        pl->scratch_bytes[m] = fa.localSizeBytes;
     }
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
@@ -357,11 +351,8 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
         pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
         PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
-        // The buffer is touched once here, on the host's time: the first launch of a plan in a fresh
-        // process otherwise returned counters off by tens at N = 1024 (the only size that parks noise here)
-        // in about four of ten runs, never a later launch -- and not once with this fill in place.
-        // (WOFDM_POISON_SCRATCH=1, developer switch: NaN patterns instead of zeros, so that a read of
-        // something this launch has not written cannot pass for noise.)
+        // zero-filled; WOFDM_POISON_SCRATCH=1 (developer switch): NaN patterns instead, so that a read of
+        // parked noise that the same launch has not written cannot pass for noise
         const char *ps = std::getenv("WOFDM_POISON_SCRATCH");
         PLAN_TRY(hipMemset(pl->d_nscr, (ps && ps[0] == '1') ? 0xFF : 0, pl->nscr_wgs * row * sizeof(float2)));
         PLAN_TRY(hipDeviceSynchronize());
