@@ -736,13 +736,17 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 // of the workgroup).  Bounded: a wave never hangs the GPU on a protocol error, it falls through.
 // A wave that gives up leaves a mark in LDS (gave_up), turned into bit 0 of the plan's status word
 // when the workgroup retires -- the only trace of this in the frame loop is the loop's own counter.
-// (the flag words are addressed as LDS, not through the generic address space: volatile accesses through a
-// generic pointer come out as flat_load / flat_store, which take the vector-memory path to the LDS and back)
-typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+// The flag words are addressed as LDS, not through the generic address space: volatile accesses through a
+// generic pointer come out as flat_load / flat_store, which take the vector-memory path to the LDS and back --
+// and with those (plus cold caches and one particular code layout) a few frames of a kernel's first launch in
+// a process came out wrong (hazard 3).  -DWOFDM_FLAT_FLAGS=1 rebuilds that form.
+#ifdef WOFDM_FLAT_FLAGS
+typedef volatile int lds_vint;
+#else
 typedef volatile __attribute__((address_space(3))) int lds_vint;
-__device__ __forceinline__ void wait_flag(const volatile int *flag_, int target, volatile int *gave_up)
+#endif
+__device__ __forceinline__ void wait_flag(const lds_vint *flag, int target, lds_vint *gave_up)
 {
-    lds_cvint *flag = (lds_cvint *)flag_;
     int budget = 1 << 22;
     while (__builtin_amdgcn_readfirstlane(*flag) < target) {
         if (__builtin_expect(--budget == 0, 0)) {
@@ -753,10 +757,10 @@ __device__ __forceinline__ void wait_flag(const volatile int *flag_, int target,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void post_flag(volatile int *flag, int value, int lane)
+__device__ __forceinline__ void post_flag(lds_vint *flag, int value, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *(lds_vint *)flag = value;
+    if (lane == 0) *flag = value;
 }
 
 __device__ __forceinline__ v2f ldg2(const float2 *p) { const float2 t = *p; return mk(t.x, t.y); }
@@ -845,6 +849,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool RELAUNDER = N >= 1024 || (N >= 512 && VAR >= 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+#ifdef WOFDM_COLD_ENTRY
+    // (developer stressor, tools/cold_launch_probe.py: a system-scope acquire -- buffer_inv sc0 sc1 -- makes every
+    // workgroup start on invalidated caches, which multiplies the rate of the first-launch fault of hazard 3)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
     const int tid = threadIdx.x, lane0 = tid & 63;
     // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -864,7 +873,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     v2f *tw = reinterpret_cast<v2f *>(smem + L::off_tw);
     v2f *G = reinterpret_cast<v2f *>(smem + L::off_g);
     float *sums = reinterpret_cast<float *>(smem + L::off_sums);
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + L::off_flags);
+    lds_vint *flags = (lds_vint *)(smem + L::off_flags);
     float *wtx = reinterpret_cast<float *>(smem + L::off_wtx);
     float *wrx = reinterpret_cast<float *>(smem + L::off_wrx);
     // (fall tails: S rows of tail_tx samples right behind the frame buffer, at a run-time offset that
@@ -986,6 +995,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #ifdef WOFDM_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef WOFDM_PAD
+    // (developer switch: the frame loop's code shifted by 4 WOFDM_PAD bytes -- with -DWOFDM_MMA_ALIGN=0 the way to
+    // put an MFMA chain across a page on purpose, hazard 3 of DESIGN.md section 4)
+    asm volatile(".rept " WOFDM_STR(WOFDM_PAD) "\n\ts_nop 0\n\t.endr");
 #endif
     for (; n_items != 0; --n_items) {
         STAMP(7);                                   // loop control, cell changes
@@ -1902,7 +1916,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const bool all_full = !DUMP && LW == 128 * NT;
             v2f *rxb = (FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B)) + jl;
             const int dlt = FIR8 ? 0 : (plen - 4 * B) / 2;
-            v2f *sink = reinterpret_cast<v2f *>(const_cast<int *>(flags) + 24);   // 16 idle bytes
+            v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
