@@ -2,8 +2,8 @@
 process came out wrong in round 2 (hazard 3) when three things met: cold caches, the
 LDS flag words accessed with flat_load / flat_store, and one particular code layout around the FIR's chain of
 dependent in-place MFMAs.  The shipped kernels keep two of the three out by construction, and this file checks
-both in the disassembly: every MFMA chain sits inside ONE 64-byte instruction-cache line, and no frame kernel
-contains a flat instruction."""
+both in the disassembly: every MFMA chain sits inside ONE 64-byte instruction-cache line, and no kernel of the
+library contains a flat instruction."""
 import os
 import re
 import shutil
@@ -64,7 +64,7 @@ def mfma_chains(co):
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump")) and shutil.which("objcopy")),
                     reason="needs the built library and the ROCm LLVM tools")
-def test_mfma_chains_sit_in_one_line_and_no_frame_kernel_uses_flat_instructions():
+def test_mfma_chains_sit_in_one_line_and_no_kernel_uses_flat_instructions():
     n_chains, n_kernels, bad, flat_in = 0, 0, [], []
     with tempfile.TemporaryDirectory() as tmp:
         for co in _code_objects(LIB, tmp):
@@ -75,10 +75,9 @@ def test_mfma_chains_sit_in_one_line_and_no_frame_kernel_uses_flat_instructions(
                 if a // 64 != (b - 1) // 64:
                     bad.append((fn[:80], hex(a)))
             for fn, n in flat.items():
-                if "wofdm_frames_kernel" in fn:
-                    n_kernels += 1
-                    if n:
-                        flat_in.append((fn[:80], n))
+                n_kernels += "wofdm_frames_kernel" in fn
+                if n:                                            # (any kernel of the library)
+                    flat_in.append((fn[:80], n))
     assert n_chains > 1000 and n_kernels == 420      # every kernel of the library was looked at
     assert not bad, bad[:5]
     assert not flat_in, flat_in[:5]
