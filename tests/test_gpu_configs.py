@@ -132,6 +132,24 @@ def test_c4_wola_n1024_64qam_cells(channels):
     assert (np.diff(ber) < 0).all() and ber[0] > 0.3
 
 
+def test_c4_at_the_references_size_adds_up(channels):
+    """C4 as the reference runs it (2 000 cells x 100 frames of 16 symbols, 3.2e6 OFDM symbols): the counters of
+    one launch equal the sum over three unequal frame ranges bit for bit, the bit totals are the closed form, and
+    the BER curve averaged over the 100 channels falls with the SNR."""
+    st = W.make_structure("WOLA", 1024, 32)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snr = (-20.0 + 3.0 * np.arange(20)).astype(np.float32)
+    h = channels.astype(np.complex64)
+    cfg = W.make_cfg(st, 6, 16, 21, 100, 20, 1, seed=4)
+    with W.Plan(cfg, w_tx, w_rx, h, snr) as plan:
+        whole = plan.run(0, 100)
+        parts = plan.run(0, 37) + plan.run(37, 1) + plan.run(38, 62)
+    assert np.array_equal(whole, parts)
+    assert (whole[..., 1] == 100 * 15 * 1024 * 6).all() and (whole[..., 3] == 100 * 15 * 1024).all()
+    ber = whole[0, :, :, 0].sum(axis=1) / whole[0, :, :, 1].sum(axis=1)
+    assert (np.diff(ber) < 0).all() and ber[0] > 0.3 and ber[-1] < 0.05
+
+
 @pytest.mark.parametrize("n_fft,k", [(256, 2), (512, 4), (1024, 6), (512, 2), (256, 6)])
 def test_c5_sweep_sample(channels, n_fft, k):
     """C5 sample: a few (N, QAM) points of the full sweep, all seven structures as window
