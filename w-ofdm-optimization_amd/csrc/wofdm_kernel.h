@@ -110,6 +110,9 @@ static inline int wofdm_nsym(int spw) { return spw == 8 ? 1 : ((spw == 5 || wofd
 #endif
 static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool firm = true)
 {
+    // (the matrix-pipe kernels take a stride of at least n_fft for granted: their tiles below SPW n_fft
+    // samples carry no validity tests)
+    firm = firm && B >= n_fft;
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return 6;
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return 7;

@@ -847,6 +847,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // vectors of one phase's FFT are kept for the next phase's -- in scratch (N = 1024: 20 spilled VGPRs
     // -> 0).  Elsewhere the recomputation costs more than it saves (N = 512: -2.5 %; C2 would spill).
     constexpr bool RELAUNDER = N >= 1024 || (N >= 512 && VAR >= 2);
+    // fewest samples a wave holds (layout 8: B >= N, wofdm_spw): tiles below that are full in every geometry and
+    // carry no validity tests.  (Not used in the quarter-wave layouts: C2 runs the all-full instantiation anyway,
+    // and the other one got 1 % slower with it.)
+    constexpr int LW_MIN = LAY == 8 ? N : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 #ifdef WOFDM_COLD_ENTRY
@@ -1656,7 +1660,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
-            const bool valid = FULLT || jr < LW;
+            // (a wave holds at least LW_MIN = SPW N samples: the tiles below that are full in every geometry)
+            bool valid = FULLT || jr < LW;
+            if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
             v2f n0, n1;
             // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
             // the next tile's operand rows are requested in between
@@ -1740,7 +1746,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 if (INJECT) {
-                    const bool valid = 128 * G + jl < LW;
+                    bool valid = 128 * G + jl < LW;
+                    if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                     noise_pair(jw + 128 * G + jl, valid, valid, nz[2 * G], nz[2 * G + 1]);
                 } else {
                     const f4 t = nscr[64 * G];
@@ -1920,7 +1927,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
-                const bool valid = all_full || jr < LW;
+                bool valid = all_full || jr < LW;
+                if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
                 v2f *dst = rxb + 128 * G + (!FIR8 && jr >= 2 * B ? dlt : 0);
