@@ -199,6 +199,169 @@ template <int P0, int P1> void sweeppage(unsigned *d_bad)
     if constexpr (P0 <= P1) { runpage<P0>(d_bad); sweeppage<P0 + 4, P1>(d_bad); }
 }
 
+
+// KIND 5: write-after-read on the chain's operands.  The B operand of MFMA number WHICH (0..5) is overwritten with
+// zeros G wait states behind the LAST MFMA of the chain: if a queued dependent MFMA fetched its operands only when
+// it starts, that term would be missing from the sum.
+template <int WHICH, int G> __global__ void __launch_bounds__(256) kwar(unsigned *bad, int iters)
+{
+    const unsigned one = 0x3C003C00u;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int s = (it * 7 + threadIdx.x / 64) & 7;
+        unsigned w[6];
+        float want = 0.f;
+        for (int m = 0; m < 6; ++m) {
+            const int v = ((s + 3 * m) & 7) + 1;
+            const _Float16 h = (_Float16)(float)v;
+            unsigned short us = __builtin_bit_cast(unsigned short, h);
+            w[m] = us | ((unsigned)us << 16);
+            want += 32.f * v;
+        }
+        float t0, t1, t2, t3;
+        asm volatile(
+            "v_mov_b32 v108, %4\n\tv_mov_b32 v109, %4\n\tv_mov_b32 v110, %4\n\tv_mov_b32 v111, %4\n\t"
+            "v_mov_b32 v112, %5\n\tv_mov_b32 v113, %5\n\tv_mov_b32 v114, %5\n\tv_mov_b32 v115, %5\n\t"
+            "v_mov_b32 v116, %6\n\tv_mov_b32 v117, %6\n\tv_mov_b32 v118, %6\n\tv_mov_b32 v119, %6\n\t"
+            "v_mov_b32 v120, %7\n\tv_mov_b32 v121, %7\n\tv_mov_b32 v122, %7\n\tv_mov_b32 v123, %7\n\t"
+            "v_mov_b32 v124, %8\n\tv_mov_b32 v125, %8\n\tv_mov_b32 v126, %8\n\tv_mov_b32 v127, %8\n\t"
+            "v_mov_b32 v128, %9\n\tv_mov_b32 v129, %9\n\tv_mov_b32 v130, %9\n\tv_mov_b32 v131, %9\n\t"
+            "v_mov_b32 v132, %10\n\tv_mov_b32 v133, %10\n\tv_mov_b32 v134, %10\n\tv_mov_b32 v135, %10\n\t"
+            "s_nop 7\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[112:115], 0\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[116:119], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[120:123], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[124:127], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[128:131], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[132:135], v[100:103]\n\t"
+            ".rept %11\n\ts_nop 0\n\t.endr\n\t"
+            "v_mov_b32 v[%12], 0\n\tv_mov_b32 v[%12 + 1], 0\n\tv_mov_b32 v[%12 + 2], 0\n\tv_mov_b32 v[%12 + 3], 0\n\t"
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+            "v_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\tv_mov_b32 %2, v102\n\tv_mov_b32 %3, v103"
+            : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3)
+            : "v"(one), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "n"(G), "n"(112 + 4 * WHICH)
+            : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
+        nbad += (t0 != want) + (t1 != want) + (t2 != want) + (t3 != want);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+template <int WHICH, int G> void runwar(unsigned *d_bad)
+{
+    hipMemset(d_bad, 0, 4);
+    kwar<WHICH, G><<<1024, 256>>>(d_bad, 200);
+    unsigned h = 0;
+    hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
+    printf("B operand of MFMA %d zeroed %2d wait states behind the chain: %u wrong sums of %.1e%s\n", WHICH, G, h, 1024.0 * 256 * 200 * 4, h ? "   <--" : "");
+}
+
+
+// KIND 6: the accumulator hops: d2 = a b1 + d1 with d1 = a b0 in DIFFERENT registers (vDst != SrcC), G wait states
+// between the two MFMAs -- what the compiler's own scheduling of a chain of builtins produces.
+template <int G> __global__ void __launch_bounds__(256) khop(unsigned *bad, int iters)
+{
+    const unsigned one = 0x3C003C00u;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int s = (it * 7 + threadIdx.x / 64) & 7;
+        unsigned w[2];
+        float want = 0.f;
+        for (int m = 0; m < 2; ++m) {
+            const int v = ((s + 3 * m) & 7) + 1;
+            const _Float16 h = (_Float16)(float)v;
+            unsigned short us = __builtin_bit_cast(unsigned short, h);
+            w[m] = us | ((unsigned)us << 16);
+            want += 32.f * v;
+        }
+        float t0, t1, t2, t3;
+        asm volatile(
+            "v_mov_b32 v108, %4\n\tv_mov_b32 v109, %4\n\tv_mov_b32 v110, %4\n\tv_mov_b32 v111, %4\n\t"
+            "v_mov_b32 v112, %5\n\tv_mov_b32 v113, %5\n\tv_mov_b32 v114, %5\n\tv_mov_b32 v115, %5\n\t"
+            "v_mov_b32 v116, %6\n\tv_mov_b32 v117, %6\n\tv_mov_b32 v118, %6\n\tv_mov_b32 v119, %6\n\t"
+            "v_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\t"
+            "s_nop 7\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[112:115], 0\n\t"
+            ".rept %7\n\ts_nop 0\n\t.endr\n\t"
+            "v_mfma_f32_16x16x32_f16 v[96:99], v[108:111], v[116:119], v[100:103]\n\t"
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+            "v_mov_b32 %0, v96\n\tv_mov_b32 %1, v97\n\tv_mov_b32 %2, v98\n\tv_mov_b32 %3, v99"
+            : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3)
+            : "v"(one), "v"(w[0]), "v"(w[1]), "n"(G)
+            : "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
+        nbad += (t0 != want) + (t1 != want) + (t2 != want) + (t3 != want);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+template <int G> void runhop(unsigned *d_bad)
+{
+    hipMemset(d_bad, 0, 4);
+    khop<G><<<1024, 256>>>(d_bad, 200);
+    unsigned h = 0;
+    hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
+    printf("accumulator hop (vDst != SrcC), %2d wait states between the MFMAs: %u wrong sums of %.1e%s\n", G, h, 1024.0 * 256 * 200 * 4, h ? "   <--" : "");
+}
+template <int G0, int G1> void sweephop(unsigned *d_bad)
+{
+    if constexpr (G0 <= G1) { runhop<G0>(d_bad); sweephop<G0 + 1, G1>(d_bad); }
+}
+
+
+// KIND 7: the result of the chain's last MFMA read by a VALU instruction G wait states behind it (16 waves per CU
+// all doing the same, so that the matrix pipe is contended).
+template <int G> __global__ void __launch_bounds__(256) kraw(unsigned *bad, int iters)
+{
+    const unsigned one = 0x3C003C00u;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int s = (it * 7 + threadIdx.x / 64) & 7;
+        unsigned w[6];
+        float want = 0.f;
+        for (int m = 0; m < 6; ++m) {
+            const int v = ((s + 3 * m) & 7) + 1;
+            const _Float16 h = (_Float16)(float)v;
+            unsigned short us = __builtin_bit_cast(unsigned short, h);
+            w[m] = us | ((unsigned)us << 16);
+            want += 32.f * v;
+        }
+        float t0, t1, t2, t3;
+        asm volatile(
+            "v_mov_b32 v108, %4\n\tv_mov_b32 v109, %4\n\tv_mov_b32 v110, %4\n\tv_mov_b32 v111, %4\n\t"
+            "v_mov_b32 v112, %5\n\tv_mov_b32 v113, %5\n\tv_mov_b32 v114, %5\n\tv_mov_b32 v115, %5\n\t"
+            "v_mov_b32 v116, %6\n\tv_mov_b32 v117, %6\n\tv_mov_b32 v118, %6\n\tv_mov_b32 v119, %6\n\t"
+            "v_mov_b32 v120, %7\n\tv_mov_b32 v121, %7\n\tv_mov_b32 v122, %7\n\tv_mov_b32 v123, %7\n\t"
+            "v_mov_b32 v124, %8\n\tv_mov_b32 v125, %8\n\tv_mov_b32 v126, %8\n\tv_mov_b32 v127, %8\n\t"
+            "v_mov_b32 v128, %9\n\tv_mov_b32 v129, %9\n\tv_mov_b32 v130, %9\n\tv_mov_b32 v131, %9\n\t"
+            "v_mov_b32 v132, %10\n\tv_mov_b32 v133, %10\n\tv_mov_b32 v134, %10\n\tv_mov_b32 v135, %10\n\t"
+            "v_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\t"
+            "s_nop 7\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[112:115], 0\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[116:119], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[120:123], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[124:127], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[128:131], v[100:103]\n\t"
+            "v_mfma_f32_16x16x32_f16 v[100:103], v[108:111], v[132:135], v[100:103]\n\t"
+            ".rept %11\n\ts_nop 0\n\t.endr\n\t"
+            "v_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\tv_mov_b32 %2, v102\n\tv_mov_b32 %3, v103\n\t"
+            "s_nop 7\n\ts_nop 7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(one), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "n"(G)
+            : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
+        nbad += (t0 != want) + (t1 != want) + (t2 != want) + (t3 != want);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+template <int G> void runraw(unsigned *d_bad)
+{
+    hipMemset(d_bad, 0, 4);
+    kraw<G><<<1024, 256>>>(d_bad, 200);
+    unsigned h = 0;
+    hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
+    printf("result read by the VALU %2d wait states behind the last MFMA: %u wrong values of %.1e%s\n", G, h, 1024.0 * 256 * 200 * 4, h ? "   <--" : "");
+}
+template <int G0, int G1> void sweepraw(unsigned *d_bad)
+{
+    if constexpr (G0 <= G1) { runraw<G0>(d_bad); sweepraw<G0 + 1, G1>(d_bad); }
+}
+
 template <int KIND, int G> void run(unsigned *d_bad)
 {
     hipMemset(d_bad, 0, 4);
@@ -217,6 +380,10 @@ int main()
 {
     unsigned *d_bad; hipMalloc(&d_bad, 4);
     sweeppage<4, 60>(d_bad);            // (first: nothing else of this code object has run yet)
+    sweepraw<0, 16>(d_bad);
+    sweephop<0, 16>(d_bad);
+    runwar<5, 0>(d_bad); runwar<5, 1>(d_bad); runwar<5, 2>(d_bad); runwar<5, 4>(d_bad); runwar<5, 8>(d_bad); runwar<5, 16>(d_bad); runwar<5, 32>(d_bad);
+    runwar<4, 0>(d_bad); runwar<4, 4>(d_bad); runwar<3, 0>(d_bad); runwar<2, 0>(d_bad); runwar<1, 0>(d_bad);
     sweep<0, 0, 24>(d_bad);
     run<0, 32>(d_bad); run<0, 48>(d_bad); run<0, 64>(d_bad); run<0, 100>(d_bad);
     sweep<1, 1, 16>(d_bad);

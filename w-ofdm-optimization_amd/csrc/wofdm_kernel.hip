@@ -88,6 +88,12 @@ namespace {
 #ifndef WOFDM_MMA_ALIGN
 #define WOFDM_MMA_ALIGN 6
 #endif
+// Wait states behind the chain: the VALU is NOT interlocked against a pending MFMA result (tools/ubench/mfma_gap.hip:
+// a VALU read fewer than 7 wait states behind the last v_mfma_f32_16x16x32_f16 returns stale registers); the
+// compiler's own rule for an 8-pass MFMA on gfx950 is 12, and inside an asm block nobody else counts them.
+#ifndef WOFDM_MMA_TAIL_EXTRA
+#define WOFDM_MMA_TAIL_EXTRA "\n\ts_nop 3"
+#endif
 
 // Developer build (-DWOFDM_DELAY, tools/delay_probe.py): chosen waves sleep at a chosen point of the frame,
 // so that a hole in the wave-to-wave synchronisation shows on every launch instead of once in a cold process.
@@ -1633,6 +1639,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // in front, the trailing one the result's latency and the operand reads of the last MFMA.
         auto fir_mma = [&](const bops &o) -> f4 {
             f4 d;
+#ifdef WOFDM_MMA_BUILTIN
+            // (developer switch: the chain as six builtins, scheduled -- and interleaved with the noise draw -- by
+            // the compiler; the form hazard 1 was first met in)
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], o.h0, (f4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], o.h1, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.l0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.l1, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.h0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.h1, d, 0, 0, 0);
+            return d;
+#endif
             asm volatile(".p2align " WOFDM_STR(WOFDM_MMA_ALIGN) "\n\t"
                          "s_nop 1\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %1, %5, 0\n\t"        // h_lo x_hi
@@ -1641,7 +1658,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                          "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %3, %5, %0\n\t"       // h_hi x_hi
                          "v_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\t"
-                         "s_nop 7"
+                         "s_nop 7" WOFDM_MMA_TAIL_EXTRA
                          : "=&v"(d)
                          : "v"(A[1]), "v"(A[3]), "v"(A[0]), "v"(A[2]), "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1));
             return d;
