@@ -1629,14 +1629,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             return o;
         };
-        // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC, the form the matrix
-        // pipe forwards back to back).  Written as a single asm block on purpose: left to the register
-        // allocator the chain hops between accumulators (vDst != SrcC), and with the unit-noise draw
-        // scheduled right behind it, FIR outputs came out sporadically wrong (a few frames in 10^4, run
-        // to run different: tools/racecheck.py) -- also with an in-place chain as six separate asm
-        // statements, i.e. whenever VALU instructions sat between the dependent MFMAs.  Back to back
-        // the chain is exact and repeatable.  The leading s_nop covers a VALU write of an operand just
-        // in front, the trailing one the result's latency and the operand reads of the last MFMA.
+        // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC).  Written as a single
+        // asm block on purpose: left to the compiler (builtins) the chain hops between accumulators and
+        // the register allocator puts an MFMA's destination on top of its own B operand -- this MFMA has no
+        // early-clobber constraint in the compiler -- and FIR outputs came out sporadically wrong (a few
+        // frames in 10^4, run to run different: tools/racecheck.py; DESIGN.md section 4, hazard 1).  Here
+        // the destination is early-clobber by hand ("=&v"), the order and the wait states are fixed: the
+        // leading s_nop covers a VALU write of an operand just in front, the trailing ones the 12 wait
+        // states a VALU read of the result needs (not interlocked: tools/ubench/mfma_gap.hip).
         auto fir_mma = [&](const bops &o) -> f4 {
             f4 d;
 #ifdef WOFDM_MMA_BUILTIN
@@ -1648,6 +1648,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.l1, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.h0, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.h1, d, 0, 0, 0);
+#if WOFDM_MMA_BUILTIN == 2
+            // (... with the result fenced by the full 12 wait states before anything may read it)
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(d));
+#elif WOFDM_MMA_BUILTIN >= 3
+            // (... and with all operands alive to the end of the chain: left alone, the register allocator puts
+            // the destination of an MFMA on top of its own B operand -- this MFMA carries no early-clobber
+            // constraint in the compiler -- and a multi-pass MFMA that overwrites an operand it is still reading
+            // is what made the compiler-scheduled chain wrong)
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(d) : "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1),
+                         "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]));
+#endif
             return d;
 #endif
             asm volatile(".p2align " WOFDM_STR(WOFDM_MMA_ALIGN) "\n\t"
