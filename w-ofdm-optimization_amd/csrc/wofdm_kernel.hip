@@ -1232,6 +1232,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const float *pW = wtx + (lane + mu);
             uint32_t *pHp = pH - N, *pLp = pL - N;
             const float *pWp = pW - N;
+            // (two instantiations: whether body copies can land in the fall tail is a property of the
+            // structure, decided once per frame instead of once per element)
+            auto tx8 = [&](auto body_tail_c) {
 #pragma unroll
             for (int q = 0; q < BPL; ++q) {
 #pragma unroll
@@ -1245,7 +1248,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         hrow[i + (tl ? DtH : 0)] = hi;
                         hrow[i + (tl ? DtL : B)] = lo;
                     };
-                    if (body_tail) {
+                    if constexpr (decltype(body_tail_c)::value) {
                         put_tail(t + mu);
                     } else {
                         split_h(x * pW[e], hi, lo);
@@ -1266,6 +1269,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                 }
             }
+            };
+            if (body_tail) tx8(std::true_type{});
+            else tx8(std::false_type{});
         } else if constexpr (FIRQ) {
             // the same copies, every sample split into its two packed-f16 words; the fall tail goes to
             // the tail planes, DtH / DtL words away from the row's word in plane H / L
@@ -1281,6 +1287,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const float *pW = wtx + (llq + mu);
             uint32_t *pHp = pH - N, *pLp = pL - N;
             const float *pWp = pW - N;
+            auto tx4 = [&](auto body_tail_c) {          // (two instantiations, as in layout 8)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1288,7 +1295,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const int tt = q + 4 * r, t = llq + 16 * tt;
                     const v2f x = v[0][q][r];
                     uint32_t hi, lo;
-                    if (body_tail) {
+                    if constexpr (decltype(body_tail_c)::value) {
                         const int i = t + mu;
                         split_h(x * wtx[i], hi, lo);
                         const bool tl = i >= Bs;
@@ -1319,6 +1326,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             }
                         }
                 }
+            };
+            if (body_tail) tx4(std::true_type{});
+            else tx4(std::false_type{});
         } else if constexpr (QW) {
             // the same copies with per-lane symbol geometry (the four quarters of the wave sit in
             // four different symbols)
