@@ -1287,7 +1287,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const float *pW = wtx + (llq + mu);
             uint32_t *pHp = pH - N, *pLp = pL - N;
             const float *pWp = pW - N;
-            auto tx4 = [&](auto body_tail_c) {          // (two instantiations, as in layout 8)
+            // (four instantiations: whether body copies can reach the fall tail, and whether prefix and suffix are
+            // at most 48 samples long -- then only three elements each can have a copy, not nine and eight: every
+            // such site is an exec-masked region with its own skip branch)
+            auto tx4 = [&](auto body_tail_c, auto small_c) {
+            constexpr int CPB = decltype(small_c)::value ? 48 : L::CPCS_MAX;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1307,7 +1311,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         pL[16 * tt] = lo;
                     }
                     // (the wave-uniform test first: most elements have no lane in the prefix / suffix)
-                    if (15 + 16 * tt >= N - L::CPCS_MAX)
+                    if (15 + 16 * tt >= N - CPB)
                         if (16 * tt + 15 >= N - mu) {
                             if (t >= N - mu) {
                                 split_h(x * pWp[16 * tt], hi, lo);
@@ -1315,7 +1319,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                                 pLp[16 * tt] = lo;
                             }
                         }
-                    if (16 * tt < L::CPCS_MAX)
+                    if (16 * tt < CPB)
                         if (16 * tt < rho) {
                             if (t < rho) {
                                 const int i = t + mu + N;
@@ -1327,8 +1331,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                 }
             };
-            if (body_tail) tx4(std::true_type{});
-            else tx4(std::false_type{});
+            const bool small = mu <= 48 && rho <= 48;
+            if (body_tail) { if (small) tx4(std::true_type{}, std::true_type{}); else tx4(std::true_type{}, std::false_type{}); }
+            else { if (small) tx4(std::false_type{}, std::true_type{}); else tx4(std::false_type{}, std::false_type{}); }
         } else if constexpr (QW) {
             // the same copies with per-lane symbol geometry (the four quarters of the wave sit in
             // four different symbols)
