@@ -77,7 +77,9 @@ typedef struct wofdm_dump {
     float   *tx;         /* [beta + S*B][2]                             */
     float   *conv;       /* [T + L - 1][2]                              */
     float   *rx;         /* [S*B][2]                                    */
-    float   *Y;          /* [S][N][2]                                   */
+    float   *Y;          /* [S][N][2]  (the kernels leave circular_shift, m:313-333, to the equaliser, which
+                          * divides the resulting per-subcarrier phase out; the dump puts that phase,
+                          * e^{+2 pi i (kappa + delta/2) n / N}, back on the host, so this IS the reference's Y) */
     float   *Xhat;       /* [S-1][N][2]                                 */
     uint8_t *labels_rx;  /* [S-1][N]                                    */
     float   *gain;       /* [1]                                         */
@@ -159,6 +161,19 @@ int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
  * the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
  * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
 int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
+
+/* Diagnostic choice among the kernels of the family (A/B measurements and the tests; the results do not depend
+ * on it beyond fp32 rounding, the defaults are the fastest kernels).  Takes effect for the launches that follow;
+ * returns WOFDM_E_UNSUPPORTED -- and leaves the plan as it was -- when no kernel fits the geometry under the option.
+ *   WOFDM_OPT_FIR_VALU       1 = the 21-tap FIR (conv, main_BER_calculation.m:260) on the VALU in every layout
+ *                            (round-1 kernels) instead of the matrix pipe; 0 = default
+ *   WOFDM_OPT_MAX_SPW        at most 1, 2 or 4 OFDM symbols per wavefront; 0 = default (the most that fits)
+ *   WOFDM_OPT_TXMASK_DIRECT  1 = the Tx mask (wofdm_plan_set_tx_mask) always as a direct-form convolution instead
+ *                            of fast convolution where that fits; 0 = default */
+#define WOFDM_OPT_FIR_VALU       0
+#define WOFDM_OPT_MAX_SPW        1
+#define WOFDM_OPT_TXMASK_DIRECT  2
+int wofdm_plan_set_option(wofdm_plan *plan, int32_t option, int32_t value);
 
 /* One-shot, host pointers in / host counters out (synchronous):
  * counts[pairs][n_snr][n_channels][4] accumulated into. */

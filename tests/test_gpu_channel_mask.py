@@ -133,9 +133,8 @@ MASK_CASES = [("wtx", 256, 32, 4), ("WOLA", 256, 22, 4), ("CPW", 64, 16, 2), ("C
 
 @pytest.mark.parametrize("system,n_fft,cp,k", MASK_CASES)
 @pytest.mark.parametrize("inject,direct", [(False, False), (True, False), (False, True)])
-def test_tx_mask_one_frame_stage_by_stage(channels, monkeypatch, system, n_fft, cp, k, inject, direct):
+def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject, direct):
     # direct: force the direct-form convolution where the fast-convolution form would be used
-    monkeypatch.setenv("WOFDM_TXMASK_DIRECT", "1" if direct else "0")
     S, seed, frame, cell = 16, 9, 777, 1
     st = W.make_structure(system, n_fft, cp)
     w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
@@ -149,6 +148,7 @@ def test_tx_mask_one_frame_stage_by_stage(channels, monkeypatch, system, n_fft, 
     oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64),
                      h[1].astype(np.complex128), float(snrs[0]), lab, noise, dump=True)
     with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plan.set_option("txmask_direct", 1 if direct else 0)
         plan.set_allocation(active)
         plan.set_tx_mask(mask)
         info = plan.info()

@@ -21,6 +21,8 @@ def run(system, n_fft, k, n_ch, n_snr, frames, cp=32, S=16, reps=3):
     cfg = W.make_cfg(st, k, S, 21, n_ch, n_snr, 1, seed=4)
     snr = (-20 + 3.0 * np.arange(n_snr)).astype(np.float32)
     with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:n_ch].astype(np.complex64), snr) as plan:
+        if os.environ.get("WOFDM_FIR_VALU") == "1":      # (tool switch: the round-1 kernels, FIR on the VALU)
+            plan.set_option("fir_valu", 1)
         counts = plan.new_counts()
         plan.launch(0, max(1, frames // 4), counts)
         torch.cuda.synchronize()

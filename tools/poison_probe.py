@@ -12,7 +12,7 @@ import torch
 import wofdm_amd as W
 torch.cuda.init()        # (torch's HIP runtime first: the helper library brings /opt/rocm's)
 torch.zeros(1, device="cuda")
-P = ctypes.CDLL(os.path.join(ROOT, "w-ofdm-optimization_amd", "libwofdm_poison.so"))
+P = ctypes.CDLL(os.path.join(ROOT, "tests", "native", "libwofdm_poison.so"))
 P.lds_poison.argtypes = [ctypes.c_uint32]
 P.lds_peek.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
 P.reg_poison.argtypes = [ctypes.c_uint32]

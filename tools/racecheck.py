@@ -23,6 +23,8 @@ w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np
 snrs = np.linspace(-5, 50, 12).astype(np.float32)
 cfg = W.make_cfg(st, 4, 16, 21, 1, 12, 1, seed=2)
 with W.Plan(cfg, w_tx, w_rx, ch[:1].astype(np.complex64), snrs) as plan:
+    if os.environ.get("WOFDM_FIR_VALU") == "1":      # (tool switch: the round-1 kernels, FIR on the VALU)
+        plan.set_option("fir_valu", 1)
     runs = [plan.run(0, F) for _ in range(R)]
     parts = plan.run(0, 1) + plan.run(1, F // 3) + plan.run(1 + F // 3, F - 1 - F // 3)
 same = all(np.array_equal(runs[0], r) for r in runs[1:]) and np.array_equal(runs[0], parts)

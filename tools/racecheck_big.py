@@ -11,6 +11,8 @@ st = W.make_structure("WOLA", n, 32)
 snrs = np.array([5.0, 15.0, 25.0], np.float32) + (k - 4) * 3.0
 cfg = W.make_cfg(st, k, 16, 21, 2, 3, 1, seed=8)
 with W.Plan(cfg, W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32), ch[11:13].astype(np.complex64), snrs) as plan:
+    if os.environ.get("WOFDM_FIR_VALU") == "1":      # (tool switch: the round-1 kernels, FIR on the VALU)
+        plan.set_option("fir_valu", 1)
     print("kernel", plan.kernel_id())
     runs = [plan.run(3, F)[..., 0].ravel() for _ in range(R)]
 ref = runs[0]

@@ -23,6 +23,8 @@ for system, n, cp, k, S in [("WOLA", 512, 32, 4, 16), ("CPwtx", 512, 20, 2, 16),
     cfg = W.make_cfg(st, k, S, 21, 2, 3, 1, seed=8)
     h = ch[11:13].astype(np.complex64)
     with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        if os.environ.get("WOFDM_FIR_VALU") == "1":      # (tool switch: the round-1 kernels, FIR on the VALU)
+            plan.set_option("fir_valu", 1)
         got = plan.run(3, F)
     osys = O.make_sys(n, k, S, st.cp, st.cs, st.tail_tx, st.tail_rx, st.prefix_rm, st.circ_shift, 21, 1)
     want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128),

@@ -1,0 +1,207 @@
+// Developer microbenchmark (hazards 1 and 3): does a chain of dependent in-place MFMAs
+// (vDst = SrcC, six v_mfma_f32_16x16x32_f16: the FIR's fir_mma block) that is NOT issued back to back disturb
+// OTHER waves of its SIMD?  One 16-wave workgroup per CU, four waves per SIMD as in the N = 1024 frame kernel:
+// waves 0..11 ("chains") run the chain over and over, with a gap of G wait states (s_nop) or one s_sleep behind
+// its POS-th MFMA, and check their own sums; waves 12..15 ("bystanders", one per SIMD) run nothing but packed
+// fp32 adds on eight register pairs (integers: exact) and check every lane of every pair after every round.
+// Prints, per variant, the chains' wrong sums and the bystanders' wrong lanes (histogram over the four 16-lane
+// rows of a wave).
+//   hipcc --offload-arch=gfx950 -O3 mfma_stall_victim.hip -o mfma_stall_victim && ./mfma_stall_victim
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// KIND 0: G x s_nop 0 behind the POS-th MFMA; KIND 1: one s_sleep G there; POS = 0: no gap at all
+#define MF(d, a, b, c) "v_mfma_f32_16x16x32_f16 " d ", " a ", " b ", " c "\n\t"
+// FORM 0: six in place on one accumulator (fir_mma as shipped in round 2); FORM 1: two accumulators, three in place on
+// each, one after the other; FORM 2: two accumulators alternating
+template <int KIND, int POS, int G, int FORM> __device__ __forceinline__ f4 chain(const h8 (&a)[4], const h8 (&b)[4])
+{
+    f4 d, e;
+#define GAPTXT(p) ".if %10 == " #p "\n\t.if %11 == 0\n\t.rept %12\n\ts_nop 0\n\t.endr\n\t.else\n\ts_sleep %12\n\t.endif\n\t.endif\n\t"
+    // (operand pattern of fir_mma: A1 h0 | A3 h1 | A0 l0 | A2 l1 | A0 h0 | A2 h1)
+    if constexpr (FORM == 0) {
+        asm volatile("s_nop 1\n\t"
+                     MF("%0", "%2", "%6", "0") GAPTXT(1) MF("%0", "%3", "%7", "%0") GAPTXT(2) MF("%0", "%4", "%8", "%0") GAPTXT(3)
+                     MF("%0", "%5", "%9", "%0") GAPTXT(4) MF("%0", "%4", "%6", "%0") GAPTXT(5) MF("%0", "%5", "%7", "%0")
+                     "s_nop 7\n\ts_nop 3"
+                     : "=&v"(d), "=&v"(e) : "v"(a[1]), "v"(a[3]), "v"(a[0]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                       "n"(POS), "n"(KIND), "n"(G));
+        return d;
+    } else if constexpr (FORM == 1) {
+        asm volatile("s_nop 1\n\t"
+                     MF("%0", "%2", "%6", "0") GAPTXT(1) MF("%0", "%3", "%7", "%0") GAPTXT(2) MF("%0", "%4", "%8", "%0") GAPTXT(3)
+                     MF("%1", "%5", "%9", "0") GAPTXT(4) MF("%1", "%4", "%6", "%1") GAPTXT(5) MF("%1", "%5", "%7", "%1")
+                     "s_nop 7\n\ts_nop 3"
+                     : "=&v"(d), "=&v"(e) : "v"(a[1]), "v"(a[3]), "v"(a[0]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                       "n"(POS), "n"(KIND), "n"(G));
+        return d + e;
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     MF("%0", "%2", "%6", "0") GAPTXT(1) MF("%1", "%3", "%7", "0") GAPTXT(2) MF("%0", "%4", "%8", "%0") GAPTXT(3)
+                     MF("%1", "%5", "%9", "%1") GAPTXT(4) MF("%0", "%4", "%6", "%0") GAPTXT(5) MF("%1", "%5", "%7", "%1")
+                     "s_nop 7\n\ts_nop 3"
+                     : "=&v"(d), "=&v"(e) : "v"(a[1]), "v"(a[3]), "v"(a[0]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                       "n"(POS), "n"(KIND), "n"(G));
+        return d + e;
+    }
+}
+
+// out[0] chains' wrong sums, out[1] bystanders' wrong (lane, pair, round) checks, out[2..5] those by 16-lane row,
+// out[6] rounds checked, out[8 + wave] HW_ID of block 0's waves
+template <int KIND, int POS, int G, int PK, int FORM = 0> __global__ void __launch_bounds__(1024) k(unsigned *out, int iters, unsigned chain_mask, unsigned by_mask)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16 * 4 * 64 * 16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && lane == 0) out[8 + wv] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    if ((chain_mask >> wv) & 1u) {
+        // the B operands come from LDS like the kernel's (one 16-byte row per lane and operand), re-read every round
+        h8 a[4], b[4];
+        h8 *rows = reinterpret_cast<h8 *>(lds) + wv * 4 * 64 + lane;
+        for (int q = 0; q < 4; ++q) {
+            h8 t;
+            for (int i = 0; i < 8; ++i) { a[q][i] = (_Float16)(float)(1 + q); t[i] = (_Float16)(float)(1 + (lane & 3)); }
+            rows[64 * q] = t;
+        }
+        // D[i][j] = sum_k A[i][k] B[k][j]: 32 products per MFMA, B's column j = lane & 15; A weights 2 4 1 3 1 3
+        const float want = 14.0f * 32.0f * (float)(1 + (lane & 3));
+        unsigned nbad = 0;
+        for (int it = 0; it < iters; ++it) {
+            for (int q = 0; q < 4; ++q) b[q] = rows[64 * q];
+            const f4 d = chain<KIND, POS, G, FORM>(a, b);
+            nbad += (d.x != want) + (d.y != want) + (d.z != want) + (d.w != want);
+            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+            asm volatile("" ::: "memory");
+        }
+        if (nbad) atomicAdd(&out[0], nbad);
+    } else if ((by_mask >> wv) & 1u) {
+        v2f x[8];
+        for (int j = 0; j < 8; ++j) x[j] = (v2f){(float)(lane + j), (float)(2 * lane + j)};
+        const v2f one = {1.0f, 1.0f};
+        unsigned nbad = 0, rounds = 0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (PK == 1) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x[j]) : "v"(one));
+                    else if (PK == 0) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(x[j].x), "+v"(x[j].y) : "v"(1.0f));
+                    else if (PK == 2) {
+                        // through LDS and back (the wave's own 64 x 8 slots), plus one
+                        v2f *slot = reinterpret_cast<v2f *>(lds) + (wv * 8 + j) * 64 + lane;
+                        *slot = x[j] + one;
+                        asm volatile("" ::: "memory");
+                        x[j] = *slot;
+                    } else if (PK == 3) {
+                        // (x.re, x.im) -> (x.re + 1, x.im + 1) as  x + (1, 1)  with the operand swizzles of the kernel's add_mi:
+                        // a + (-i) d with d = (-1, 1): (a.x + d.y, a.y - d.x)
+                        v2f r;
+                        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x[j]), "v"((v2f){-1.0f, 1.0f}));
+                        x[j] = r;
+                    } else if (PK == 4) {         // op_sel only: (a.x + d.y, a.y + d.x), d = (1, 1)
+                        v2f r;
+                        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x[j]), "v"(one));
+                        x[j] = r;
+                    } else if (PK == 5) {         // neg only: (a.x - d.x, a.y - d.y), d = (-1, -1)
+                        v2f r;
+                        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x[j]), "v"((v2f){-1.0f, -1.0f}));
+                        x[j] = r;
+                    } else if (PK == 6) {         // out of place, no modifier
+                        v2f r;
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x[j]), "v"(one));
+                        x[j] = r;
+                    } else {                      // v_pk_fma_f32 with the swizzles of cmul's second instruction: a * (1, 1) + (1, 1)
+                        v2f r;
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x[j]), "v"(one));
+                        x[j] = r;
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w0 = (float)(lane + j) + 16.0f, w1 = (float)(2 * lane + j) + 16.0f;
+                nbad += (x[j].x != w0) + (x[j].y != w1);
+                x[j] = (v2f){(float)(lane + j), (float)(2 * lane + j)};
+                asm volatile("" : "+v"(x[j]));
+            }
+            ++rounds;
+        }
+        if (nbad) { atomicAdd(&out[1], nbad); atomicAdd(&out[2 + (lane >> 4)], nbad); }
+        if (lane == 0 && blockIdx.x == 0) out[6] = rounds;
+    }
+}
+
+template <int KIND, int POS, int G, int PK, int FORM = 0> void run(const char *what, unsigned chain_mask = 0x0FFFu, unsigned by_mask = 0xF000u)
+{
+    unsigned *d;
+    hipMalloc(&d, 64 * sizeof(unsigned));
+    hipMemset(d, 0, 64 * sizeof(unsigned));
+    const int iters = 20000;
+    hipLaunchKernelGGL((k<KIND, POS, G, PK, FORM>), dim3(256), dim3(1024), 0, 0, d, iters, chain_mask, by_mask);
+    hipDeviceSynchronize();
+    std::vector<unsigned> h(64);
+    hipMemcpy(h.data(), d, 64 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    printf("%-44s chains' wrong sums %8u of %.2e; bystanders' wrong values %8u of %.2e (by lane row: %u %u %u %u)\n", what, h[0],
+           256.0 * __builtin_popcount(chain_mask) * 64 * 4 * iters, h[1], 256.0 * __builtin_popcount(by_mask) * 64 * 16 * iters, h[2], h[3], h[4], h[5]);
+    static bool first = true;
+    if (first && POS == 0) {
+        first = false;
+        printf("   (block 0: SIMD of waves 0..15 from HW_ID[5:4]:");
+        for (int w = 0; w < 16; ++w) printf(" %u", (h[8 + w] >> 4) & 3);
+        printf(")\n");
+    }
+    hipFree(d);
+}
+
+int main()
+{
+    // 1) gap length behind the fifth MFMA; bystanders: v_pk_add_f32 with the kernel's add_mi modifiers (op_sel + neg)
+    run<0, 0, 0, 3>("no gap, swizzled pk_add");
+    run<0, 5, 1, 3>("1 wait state behind MFMA 5");
+    run<0, 5, 2, 3>("2 wait states behind MFMA 5");
+    run<0, 5, 4, 3>("4 wait states behind MFMA 5");
+    run<0, 5, 6, 3>("6 wait states behind MFMA 5");
+    run<0, 5, 7, 3>("7 wait states behind MFMA 5");
+    run<0, 5, 8, 3>("8 wait states behind MFMA 5");
+    run<0, 5, 12, 3>("12 wait states behind MFMA 5");
+    run<0, 5, 16, 3>("16 wait states behind MFMA 5");
+    run<0, 5, 32, 3>("32 wait states behind MFMA 5");
+    run<0, 5, 64, 3>("64 wait states behind MFMA 5");
+    run<1, 5, 1, 3>("s_sleep 1 behind MFMA 5");
+    // 2) position of a 16-wait-state gap
+    run<0, 1, 16, 3>("16 wait states behind MFMA 1");
+    run<0, 2, 16, 3>("16 wait states behind MFMA 2");
+    run<0, 3, 16, 3>("16 wait states behind MFMA 3");
+    run<0, 4, 16, 3>("16 wait states behind MFMA 4");
+    // 3) which instructions of the bystander are hit (16 wait states behind MFMA 5)
+    run<0, 5, 16, 1>("  v_pk_add_f32 in place, no modifier");
+    run<0, 5, 16, 6>("  v_pk_add_f32 out of place, no modifier");
+    run<0, 5, 16, 4>("  v_pk_add_f32 op_sel only");
+    run<0, 5, 16, 5>("  v_pk_add_f32 neg only");
+    run<0, 5, 16, 7>("  v_pk_fma_f32 op_sel");
+    run<0, 5, 16, 0>("  v_add_f32");
+    run<0, 5, 16, 2>("  LDS round trips (ds_write_b64 / ds_read_b64)");
+    // 4) who has to share what
+    run<0, 5, 16, 3>("16 ws, ONE chain wave (0), bystanders 12..15", 0x0001u, 0xF000u);
+    run<0, 5, 16, 3>("16 ws, chain wave 0, bystander 4 (same SIMD)", 0x0001u, 0x0010u);
+    run<0, 5, 16, 3>("16 ws, chain wave 0, bystander 1 (other SIMD)", 0x0001u, 0x0002u);
+    // 5) other forms of the same sum: two accumulators, 3 + 3 one after the other / alternating
+    run<0, 0, 0, 3, 1>("3+3, no gap");
+    run<0, 3, 16, 3, 1>("3+3, 16 ws behind MFMA 3");
+    run<0, 4, 16, 3, 1>("3+3, 16 ws behind MFMA 4");
+    run<0, 5, 16, 3, 1>("3+3, 16 ws behind MFMA 5");
+    run<0, 0, 0, 3, 2>("alternating, no gap");
+    run<0, 3, 16, 3, 2>("alternating, 16 ws behind MFMA 3");
+    run<0, 4, 16, 3, 2>("alternating, 16 ws behind MFMA 4");
+    run<0, 5, 16, 3, 2>("alternating, 16 ws behind MFMA 5");
+    // 6) can ARBITRATION alone open such a gap?  No gap in the code; the bystanders are the OLDER waves of their SIMDs
+    //    (oldest-first issue), busy with independent swizzled packed adds / fmas, the chains are the youngest
+    run<0, 0, 0, 3>("no gap, bystanders 0..3 (oldest), chains 4..15", 0xFFF0u, 0x000Fu);
+    run<0, 0, 0, 3>("no gap, bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+    run<0, 0, 0, 7>("no gap, pk_fma bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+    run<0, 5, 6, 3>("6 ws behind MFMA 5, bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+    run<0, 5, 16, 3>("16 ws behind MFMA 5, bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+    return 0;
+}

@@ -18,6 +18,8 @@ _LIB = None
 WOFDM_OK = 0
 ERRORS = {-1: "WOFDM_E_INVALID", -2: "WOFDM_E_UNSUPPORTED", -3: "WOFDM_E_HIP", -4: "WOFDM_E_NOMEM"}
 MAX_TAPS = 21
+#: wofdm_plan_set_option: diagnostic kernel choice (include/wofdm.h)
+OPTIONS = {"fir_valu": 0, "max_spw": 1, "txmask_direct": 2}
 MAX_SYMS = 16
 
 #: every symbol include/wofdm.h declares (tests check the .so exports them all)
@@ -26,7 +28,7 @@ EXPORTS = (
     "wofdm_plan_create", "wofdm_plan_destroy", "wofdm_plan_launch", "wofdm_plan_launch_timed",
     "wofdm_plan_launch_injected", "wofdm_plan_dump_frame", "wofdm_plan_info", "wofdm_run",
     "wofdm_run_injected", "wofdm_philox_kat", "wofdm_plan_set_allocation",
-    "wofdm_plan_set_tx_mask", "wofdm_plan_status", "wofdm_plan_kernel_id",
+    "wofdm_plan_set_tx_mask", "wofdm_plan_status", "wofdm_plan_kernel_id", "wofdm_plan_set_option",
     "wofdm_interference", "wofdm_tx_psd",
 )
 
@@ -119,6 +121,7 @@ def load():
     L.wofdm_plan_set_allocation.argtypes = [vp, vp]
     L.wofdm_plan_set_tx_mask.argtypes = [vp, vp]
     L.wofdm_plan_status.argtypes = [vp]
+    L.wofdm_plan_set_option.argtypes = [vp, C.c_int32, C.c_int32]
     L.wofdm_run.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp]
     L.wofdm_run_injected.argtypes = [C.POINTER(Cfg), C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.wofdm_philox_kat.argtypes = [C.c_int, vp, vp, vp]

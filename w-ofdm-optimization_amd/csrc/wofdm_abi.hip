@@ -88,12 +88,15 @@ struct wofdm_plan {
     float2 *d_h = nullptr;
     int *d_geo = nullptr;
     float2 *d_nscr = nullptr;          // unit-noise scratch rows, one per workgroup (large DFTs)
-    uint64_t nscr_wgs = 0;
+    uint64_t nscr_elems = 0;           // float2 elements allocated there
     wofdm_kparams base{};
     wofdm_kernel_fn fn[4] = {nullptr, nullptr, nullptr, nullptr};   // kernels of the variant in use
     int var = WOFDM_VAR_PLAIN;         // kernel variant in use (configure())
     bool has_alloc = false, has_mask = false;
-    bool force_direct_mask = false;    // WOFDM_TXMASK_DIRECT=1 (developer switch): never the FFT form
+    // wofdm_plan_set_option: diagnostic kernel choice
+    bool force_direct_mask = false;    // WOFDM_OPT_TXMASK_DIRECT: never the FFT form
+    bool fir_valu = false;             // WOFDM_OPT_FIR_VALU: FIR on the VALU in every layout
+    int max_spw = 0;                   // WOFDM_OPT_MAX_SPW: 0 = no cap
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
@@ -120,12 +123,10 @@ int configure(wofdm_plan *pl)
     const int var = pl->has_mask ? (fft_ok ? WOFDM_VAR_TXFFT : WOFDM_VAR_TXMASK)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
-    const char *cap = std::getenv("WOFDM_SPW_CAP");          // developer switch: 1, 2 or 4
-    const char *fv = std::getenv("WOFDM_FIR_VALU");          // developer switch: 1 = FIR on the VALU everywhere
-    const bool firm = !(fv && fv[0] == '1');
+    const bool firm = !pl->fir_valu;
     int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm);
-    if (cap && cap[0] >= '1' && cap[0] <= '4' && wofdm_nsym(spw) > cap[0] - '0')
-        spw = (cap[0] == '1') ? 1 : wofdm_spw(g.N, g.S, g.B, false);
+    if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
+        spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
                          + (var == WOFDM_VAR_TXFFT ? wofdm_txfft_lds_bytes() : 0u);
@@ -167,12 +168,12 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     if (grid > total_items) grid = total_items;
     if (force_grid > 0) grid = (uint64_t)force_grid;
     const size_t row = wofdm_noise_scratch_len(pl->g.N, pl->spw);
-    if (row && grid > pl->nscr_wgs) {       // only a forced grid can outgrow the plan's scratch
+    if (row && grid * row > pl->nscr_elems) {       // only a forced grid can outgrow the plan's scratch
         HIP_TRY(hipDeviceSynchronize());
         if (pl->d_nscr) (void)hipFree(pl->d_nscr);
-        pl->d_nscr = nullptr; pl->nscr_wgs = 0;
+        pl->d_nscr = nullptr; pl->nscr_elems = 0;
         HIP_TRY(hipMalloc(&pl->d_nscr, grid * row * sizeof(float2)));
-        pl->nscr_wgs = grid;
+        pl->nscr_elems = grid * row;
     }
     kp.noise_scratch = pl->d_nscr;
     kp.status = pl->d_status;
@@ -349,12 +350,9 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     }
     const int occ = pl->occ;
     if (const size_t row = wofdm_noise_scratch_len(g.N, pl->spw)) {
-        pl->nscr_wgs = (uint64_t)pl->cus * (uint64_t)occ;
-        PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_wgs * row * sizeof(float2)));
-        // zero-filled; WOFDM_POISON_SCRATCH=1 (developer switch): NaN patterns instead, so that a read of
-        // parked noise that the same launch has not written cannot pass for noise
-        const char *ps = std::getenv("WOFDM_POISON_SCRATCH");
-        PLAN_TRY(hipMemset(pl->d_nscr, (ps && ps[0] == '1') ? 0xFF : 0, pl->nscr_wgs * row * sizeof(float2)));
+        pl->nscr_elems = (uint64_t)pl->cus * (uint64_t)occ * row;
+        PLAN_TRY(hipMalloc(&pl->d_nscr, pl->nscr_elems * sizeof(float2)));
+        PLAN_TRY(hipMemset(pl->d_nscr, 0, pl->nscr_elems * sizeof(float2)));
         PLAN_TRY(hipDeviceSynchronize());
     }
 #undef PLAN_TRY
@@ -475,11 +473,43 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
         HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)2 * NQ * sizeof(uint32_t)));
     }
     const bool had = pl->has_mask;
-    const char *fd = std::getenv("WOFDM_TXMASK_DIRECT");
-    pl->force_direct_mask = fd && fd[0] == '1';
     pl->has_mask = true;
     const int rc = configure(pl);
     if (rc != WOFDM_OK) pl->has_mask = had;
+    return rc;
+}
+
+int wofdm_plan_set_option(wofdm_plan *pl, int32_t option, int32_t value)
+{
+    if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
+    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(hipDeviceSynchronize());           // no launch of this plan may still be running on the old choice
+    const bool direct = pl->force_direct_mask, valu = pl->fir_valu;
+    const int cap = pl->max_spw;
+    switch (option) {
+    case WOFDM_OPT_FIR_VALU: pl->fir_valu = value != 0; break;
+    case WOFDM_OPT_MAX_SPW:
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(WOFDM_E_INVALID, "WOFDM_OPT_MAX_SPW takes 0, 1, 2 or 4");
+        pl->max_spw = value;
+        break;
+    case WOFDM_OPT_TXMASK_DIRECT: pl->force_direct_mask = value != 0; break;
+    default: return fail(WOFDM_E_INVALID, "unknown option %d", (int)option);
+    }
+    const int rc = configure(pl);
+    if (rc != WOFDM_OK) { pl->force_direct_mask = direct; pl->fir_valu = valu; pl->max_spw = cap; }
+    // (the noise scratch rows are sized per layout: a forced grid in launch() regrows them, a new layout here)
+    if (rc == WOFDM_OK) {
+        const size_t row = wofdm_noise_scratch_len(pl->g.N, pl->spw);
+        const uint64_t wgs = (uint64_t)pl->cus * (uint64_t)pl->occ;
+        if (row && wgs * row > pl->nscr_elems) {
+            if (pl->d_nscr) (void)hipFree(pl->d_nscr);
+            pl->d_nscr = nullptr; pl->nscr_elems = 0;
+            HIP_TRY(hipMalloc(&pl->d_nscr, wgs * row * sizeof(float2)));
+            HIP_TRY(hipMemset(pl->d_nscr, 0, wgs * row * sizeof(float2)));
+            pl->nscr_elems = wgs * row;
+        }
+    }
     return rc;
 }
 
@@ -624,6 +654,21 @@ int wofdm_plan_dump_frame(wofdm_plan *pl, uint32_t cell, uint64_t frame, const u
                   down(out->gain, kp.dump.gain, 4) && down(out->labels_tx, kp.dump.labels_tx, SN) &&
                   down(out->labels_rx, kp.dump.labels_rx, SN - g.N);
         if (!ok) { rc = fail(WOFDM_E_HIP, "hipMemcpy of dump failed"); break; }
+        // The kernels (instrumented and production alike) leave the circular shift of the Rx chain (m:313-333) out:
+        // their Y is the reference's times e^{-2 pi i (kappa + delta/2) n / N} on every symbol, which the one-tap
+        // equaliser divides out.  The dump hands the reference's Y back: the ramp is undone here, on the host.
+        if (out->Y && (g.kappa + g.delta / 2) % g.N != 0) {
+            const int c = (g.kappa + g.delta / 2) % g.N;
+            for (int n = 0; n < g.N; ++n) {
+                const double a = 2.0 * M_PI * (double)(((long long)c * n) % g.N) / (double)g.N;
+                const float cr = (float)std::cos(a), ci = (float)std::sin(a);
+                for (int sy = 0; sy < g.S; ++sy) {
+                    float *y = out->Y + 2 * ((size_t)sy * g.N + n);
+                    const float re = y[0] * cr - y[1] * ci, im = y[0] * ci + y[1] * cr;
+                    y[0] = re; y[1] = im;
+                }
+            }
+        }
         for (int i = 0; i < 4; ++i) counts[i] += c4[i];
     } while (0);
     (void)hipFree(arena);

@@ -1,29 +1,32 @@
 // wofdm_kernel.hip -- the fused w-OFDM frame kernel for gfx950 (MI355X, CDNA4).
 //
 // One workgroup simulates one frame at a time (persistent over a contiguous run of the
-// cell-major (cell, frame) work items); one 64-lane wavefront owns one or two OFDM symbols of
-// the frame:
+// cell-major (cell, frame) work items); one 64-lane wavefront owns one, two or four OFDM symbols of
+// the frame (layout ids: wofdm_kernel.h):
 //
-//   A  Philox bits -> Gray QAM (registers) -> N-point Stockham IFFT through the wave's own
-//      slice of the LDS frame buffer -> CP/CS copy x Tx window written straight from the
-//      last butterfly stage; the beta-sample fall tail goes to a side buffer
+//   A  Philox bits -> Gray QAM (registers) -> N-point IFFT (in-register 8/16-point DFT stages, one or two
+//      exchanges through the wave's own slice of the LDS frame buffer) -> CP/CS copy x Tx window written
+//      straight from the last stage, in the matrix-pipe layouts split into two packed-f16 words per sample;
+//      the beta-sample fall tail goes to a side buffer
 //      (matlab/main_BER_calculation.m:246-252, 358-376, 419-439)
 //   -- "barrier" 1: LDS flag of the predecessor wave --
 //   B  add the previous symbol's fall tail onto the own rise tail (overlap-add, m:253-259),
-//      21-tap complex FIR over the serialised frame from LDS (conv, m:260), Philox/Box-Muller
-//      unit noise for the same samples, per-wave partial signal/noise powers (add_wgn, m:277-294)
+//      21-tap complex FIR over the serialised frame (conv, m:260): on the matrix pipe as a block-Toeplitz
+//      product in split f16 with fp32 accumulation (layouts 6, 7, 8: six v_mfma_f32_16x16x32_f16 per 128
+//      samples), on the VALU from LDS in the others; Philox/Box-Muller unit noise for the same samples,
+//      per-wave partial signal/noise powers (add_wgn, m:277-294)
 //   -- barrier 2 --
-//   C  r = c + g n back into the own slice (truncate + reshape, m:261-263), Rx window / fold /
-//      circular shift fused into the first FFT stage's loads (m:297-355), Stockham FFT, pilot
-//      wave publishes X0/Y0 (m:266)
+//   C  r = c + g n back into the own slice (truncate + reshape, m:261-263), Rx window / fold fused into the
+//      first FFT stage's loads (m:297-355; the circular shift is left to the equaliser, see phase C), FFT,
+//      pilot wave publishes X0/Y0 (m:266)
 //   -- "barrier" 3: LDS flag of the pilot wave --
 //   D  one-tap equalise, hard demap, bit/symbol error popcount in registers (m:267-272)
 //
 // No HBM traffic inside the loop in generate mode (N = 1024 parks its unit noise in an L2-resident
 // scratch row): constants come in once per cell, four 64-bit counters go out once per cell.
-// fp32 VALU + LDS bound; no MFMA.  Template variants add the subcarrier allocation and the
-// per-symbol spectral Tx mask of main_channel_mask.m (VAR), injected randomness (INJECT) and
-// stage dumps (DUMP).
+// Bound by fp32 VALU issue and LDS; the matrix pipe carries the FIR only.  Template variants add the
+// subcarrier allocation and the per-symbol spectral Tx mask of main_channel_mask.m (VAR), injected
+// randomness (INJECT) and stage dumps (DUMP).
 #include "wofdm_kernel.h"
 #include "philox.h"
 #include <type_traits>
@@ -78,23 +81,14 @@ namespace {
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
 #endif
 
-#define WOFDM_STR_(x) #x
-#define WOFDM_STR(x) WOFDM_STR_(x)
-// The FIR's chain of six dependent in-place MFMAs (fir_mma) starts on a 64-byte boundary, so that the whole
-// block -- 56 bytes -- sits in ONE instruction-cache line and one page: an instruction fetch that stalls in
-// the middle of the chain (the chain of one kernel straddled a 4 KB page, whose translation is not cached on
-// a kernel's first launch in a process) left wrong sums in a few frames of that launch.  DESIGN.md section 4;
-// -DWOFDM_MMA_ALIGN=0 rebuilds the unaligned code for tools/cold_launch_probe.py.
-#ifndef WOFDM_MMA_ALIGN
-#define WOFDM_MMA_ALIGN 6
-#endif
-// Wait states behind the chain: the VALU is NOT interlocked against a pending MFMA result (tools/ubench/mfma_gap.hip:
-// a VALU read fewer than 7 wait states behind the last v_mfma_f32_16x16x32_f16 returns stale registers); the
-// compiler's own rule for an 8-pass MFMA on gfx950 is 12, and inside an asm block nobody else counts them.
-#ifndef WOFDM_MMA_TAIL_EXTRA
-#define WOFDM_MMA_TAIL_EXTRA "\n\ts_nop 3"
-#endif
-
+// The FIR's six MFMAs of a tile (fir_mma) are ONE asm block that starts on a 64-byte boundary: its 60 bytes sit in one
+// instruction-cache line, so that no instruction fetch can fall between two of them.  Measured on gfx950
+// (tools/ubench/mfma_stall_victim.hip, profiles/r03_mfma_stall_victim.txt): when 7 or more wait
+// states pass between the fourth or a later MFMA of such a run and the dependent one behind it -- an instruction-fetch
+// miss, an s_sleep, VALU instructions scheduled in between -- VOP3P instructions with op_sel (the packed complex
+// arithmetic below) executed meanwhile by OTHER waves of the same SIMD return wrong values in lanes 48..63.  The chain
+// itself stays exact; up to 6 wait states, and any delay by issue arbitration alone, are harmless.
+#define WOFDM_MMA_ALIGN "6"
 // Developer build (-DWOFDM_DELAY, tools/delay_probe.py): chosen waves sleep at a chosen point of the frame,
 // so that a hole in the wave-to-wave synchronisation shows on every launch instead of once in a cold process.
 #ifdef WOFDM_DELAY
@@ -115,9 +109,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 
-// Matrix-pipe FIR (layouts 6, 7): samples travel through LDS as two packed-f16 words, y = hi + lo
-// with both halves rounded to nearest: |y - hi - lo| <= 2^-24 |y|, so that three f16 MFMA terms
-// (h_hi x_hi + h_hi x_lo + h_lo x_hi, fp32 accumulation) reproduce the fp32 product to ~2^-23.
+// Matrix-pipe FIR (layouts 6, 7, 8): samples travel through LDS as two packed-f16 words, y = hi + lo with both
+// halves rounded to nearest: two 11-bit significands, |y - hi - lo| <= 2^-22 |y|.  Three f16 MFMA terms
+// (h_hi x_hi + h_hi x_lo + h_lo x_hi, fp32 accumulation) drop h_lo x_lo, another 2^-22: a product is good to about
+// 2^-21, four times coarser than an fp32 product -- measured on whole frames against fp64 arithmetic: conv off by
+// 2e-7 of its largest sample (tests/test_gpu_parity.py::test_fir_precision_matrix_pipe_vs_valu).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -742,15 +738,9 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
 // of the workgroup).  Bounded: a wave never hangs the GPU on a protocol error, it falls through.
 // A wave that gives up leaves a mark in LDS (gave_up), turned into bit 0 of the plan's status word
 // when the workgroup retires -- the only trace of this in the frame loop is the loop's own counter.
-// The flag words are addressed as LDS, not through the generic address space: volatile accesses through a
-// generic pointer come out as flat_load / flat_store, which take the vector-memory path to the LDS and back --
-// and with those (plus cold caches and one particular code layout) a few frames of a kernel's first launch in
-// a process came out wrong (hazard 3).  -DWOFDM_FLAT_FLAGS=1 rebuilds that form.
-#ifdef WOFDM_FLAT_FLAGS
-typedef volatile int lds_vint;
-#else
+// The flag words are addressed as LDS (ds_read / ds_write), not through the generic address space (flat_*: the vector-memory
+// path to the LDS and back).
 typedef volatile __attribute__((address_space(3))) int lds_vint;
-#endif
 __device__ __forceinline__ void wait_flag(const lds_vint *flag, int target, lds_vint *gave_up)
 {
     int budget = 1 << 22;
@@ -859,11 +849,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr int LW_MIN = LAY == 8 ? N : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-#ifdef WOFDM_COLD_ENTRY
-    // (developer stressor, tools/cold_launch_probe.py: a system-scope acquire -- buffer_inv sc0 sc1 -- makes every
-    // workgroup start on invalidated caches, which multiplies the rate of the first-launch fault of hazard 3)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-#endif
     const int tid = threadIdx.x, lane0 = tid & 63;
     // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1005,11 +990,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #ifdef WOFDM_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef WOFDM_PAD
-    // (developer switch: the frame loop's code shifted by 4 WOFDM_PAD bytes -- with -DWOFDM_MMA_ALIGN=0 the way to
-    // put an MFMA chain across a page on purpose, hazard 3 of DESIGN.md section 4)
-    asm volatile(".rept " WOFDM_STR(WOFDM_PAD) "\n\ts_nop 0\n\t.endr");
 #endif
     for (; n_items != 0; --n_items) {
         STAMP(7);                                   // loop control, cell changes
@@ -1644,39 +1624,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             return o;
         };
-        // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC).  Written as a single
-        // asm block on purpose: left to the compiler (builtins) the chain hops between accumulators and
-        // the register allocator puts an MFMA's destination on top of its own B operand -- this MFMA has no
-        // early-clobber constraint in the compiler -- and FIR outputs came out sporadically wrong (a few
-        // frames in 10^4, run to run different: tools/racecheck.py; DESIGN.md section 4, hazard 1).  Here
-        // the destination is early-clobber by hand ("=&v"), the order and the wait states are fixed: the
-        // leading s_nop covers a VALU write of an operand just in front, the trailing ones the 12 wait
-        // states a VALU read of the result needs (not interlocked: tools/ubench/mfma_gap.hip).
+        // The six MFMAs of a tile as ONE in-place accumulation chain (vDst = SrcC), written as a single asm block:
+        //  * back to back: a gap of 7 or more wait states in front of one of the later MFMAs of the run corrupts packed
+        //    op_sel arithmetic of the SIMD's other waves (see WOFDM_MMA_ALIGN above) -- left to the compiler (builtins) the
+        //    chain was interleaved with the noise draw's VALU work, and round 2's "sporadically wrong frames" were that;
+        //  * the destination early-clobber by hand ("=&v"): this MFMA carries no such constraint in the compiler, which
+        //    then puts a destination on top of the instruction's own B operand;
+        //  * the leading s_nop covers a VALU write of an operand just in front, the trailing ones the 12 wait states a
+        //    VALU read of the result needs (not interlocked: tools/ubench/mfma_gap.hip).
         auto fir_mma = [&](const bops &o) -> f4 {
             f4 d;
-#ifdef WOFDM_MMA_BUILTIN
-            // (developer switch: the chain as six builtins, scheduled -- and interleaved with the noise draw -- by
-            // the compiler; the form hazard 1 was first met in)
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], o.h0, (f4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], o.h1, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.l0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.l1, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.h0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.h1, d, 0, 0, 0);
-#if WOFDM_MMA_BUILTIN == 2
-            // (... with the result fenced by the full 12 wait states before anything may read it)
-            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(d));
-#elif WOFDM_MMA_BUILTIN >= 3
-            // (... and with all operands alive to the end of the chain: left alone, the register allocator puts
-            // the destination of an MFMA on top of its own B operand -- this MFMA carries no early-clobber
-            // constraint in the compiler -- and a multi-pass MFMA that overwrites an operand it is still reading
-            // is what made the compiler-scheduled chain wrong)
-            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(d) : "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1),
-                         "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]));
-#endif
-            return d;
-#endif
-            asm volatile(".p2align " WOFDM_STR(WOFDM_MMA_ALIGN) "\n\t"
+            asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
                          "s_nop 1\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %1, %5, 0\n\t"        // h_lo x_hi
                          "v_mfma_f32_16x16x32_f16 %0, %2, %6, %0\n\t"
@@ -1684,7 +1642,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                          "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %3, %5, %0\n\t"       // h_hi x_hi
                          "v_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\t"
-                         "s_nop 7" WOFDM_MMA_TAIL_EXTRA
+                         "s_nop 7\n\ts_nop 3"
                          : "=&v"(d)
                          : "v"(A[1]), "v"(A[3]), "v"(A[0]), "v"(A[2]), "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1));
             return d;
@@ -2009,50 +1967,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
         const int h2 = delta >> 1;
-        // Production kernels leave the circular shift out: z'[t] = z[t - kappa - delta/2] turns into the
-        // factor e^{-2 pi i (kappa + delta/2) n / N} on subcarrier n of EVERY symbol of the frame, the
-        // pilot included, and the one-tap equaliser X^[s] = Y[s] X0 / Y0 (m:266-268) divides it out again.
-        // Without it the lane's elements sit at fixed offsets from one per-lane base (addresses as
-        // instruction immediates), and only the first tail_rx <= 64 samples of a symbol can have a folded
-        // partner.  The instrumented kernels keep the shift: their Y is compared with the reference's.
-        if constexpr (DUMP) {
-            // (two passes: all main-tap loads in flight together, free of branches; the folded samples
-            // only where there is an Rx tail at all)
-#pragma unroll
-            for (int u = 0; u < VS; ++u) {
-                const v2f *fb = row(sym_of(u) - s0);
-#pragma unroll
-                for (int q = 0; q < VB; ++q) {
-                    if (owns(q)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
-                            v[u][q][r] = fb[gam + m0] * wrx[m0];
-                        }
-                    }
-                }
-            }
-            if (delta > 0) {
-#pragma unroll
-                for (int u = 0; u < VS; ++u) {
-                    const v2f *fb = row(sym_of(u) - s0);
-#pragma unroll
-                    for (int q = 0; q < VB; ++q) {
-                        if (owns(q)) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int m0 = (sub_of(q, r) + kap + h2) & (N - 1);
-                                if (m0 < delta) {
-                                    const float w2 = wrx[m0 + N];
-                                    v[u][q][r] = __builtin_elementwise_fma(mk(w2, w2), fb[gam + m0 + N], v[u][q][r]);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            (void)kap;
+        // The circular shift is left out, in the instrumented kernels as well: z'[t] = z[t - kappa - delta/2] turns into
+        // the factor e^{-2 pi i (kappa + delta/2) n / N} on subcarrier n of EVERY symbol of the frame, the pilot included,
+        // and the one-tap equaliser X^[s] = Y[s] X0 / Y0 (m:266-268) divides it out again.  Without it the lane's
+        // elements sit at fixed offsets from one per-lane base (addresses as instruction immediates), and only the
+        // first tail_rx <= 64 samples of a symbol can have a folded partner.  (The dumped Y is therefore the
+        // reference's Y times that ramp -- the tests put it back on the host; Xhat and everything behind it is the
+        // reference's.)  Two passes: all main-tap loads in flight together, free of branches; the folded samples only
+        // where there is an Rx tail at all.
+        {
+            (void)kap; (void)h2;
             const int l0 = QW ? llq : lane;                      // the lane's first element of a symbol
 #pragma unroll
             for (int u = 0; u < VS; ++u) {

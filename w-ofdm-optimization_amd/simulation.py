@@ -117,6 +117,11 @@ class Plan:
         m = _lib.f32(np.asarray(mask).reshape(-1), (2 * self.cfg.sym_len - 1,))
         _lib.check(self.lib.wofdm_plan_set_tx_mask(self._h_plan, m.ctypes.data))
 
+    def set_option(self, name, value):
+        """Diagnostic kernel choice (``wofdm_plan_set_option``): ``fir_valu`` 0/1, ``max_spw`` 0/1/2/4,
+        ``txmask_direct`` 0/1.  Same results, other kernels of the family (A/B measurements, tests)."""
+        _lib.check(self.lib.wofdm_plan_set_option(self._h_plan, _lib.OPTIONS[name], int(value)))
+
     def new_counts(self):
         """Zeroed device counter tensor [pairs][n_snr][n_channels][4] (int64 bit pattern of the
         kernel's uint64 counters; torch is only the allocator here)."""
