@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector peak (= fp32 MFMA dense peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 / bf16 matrix peak (no sparsity)
 FRAMES_PER_STEP = 62500           # x 16 symbols = 1e6 OFDM symbols per SNR point
 SNR_DB = np.arange(-5.0, 51.0, 5.0)
 
@@ -174,15 +175,33 @@ def main():
     if rank == 0:
         # HBM bytes per launch come from rocprofv3 PMC passes (not collectable from inside this run):
         # the committed figure is used only while it was measured on exactly these kernel sources
-        traffic = None
+        traffic, pipes = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_source_hash") == W.kernel_source_hash():
                     traffic = tj.get("bytes_per_launch")
+                    # What the two pipes actually ISSUE (PMC counts of the same launch x this run's launch rate): the
+                    # algorithmic figure above charges the FIR's fp32 flop although it executes as f16 MFMAs.
+                    vi, mi = tj.get("valu_insts_per_launch"), tj.get("mfma_insts_per_launch")
+                    va, ga = tj.get("valu_active_quadcycles_per_launch"), tj.get("gui_active_cycles_per_launch")
+                    if vi and mi:
+                        per_s = 1.0 / (avg_ms * 1e-3)
+                        simds = 1024
+                        pipes = {
+                            "valu": {"wave_insts_per_symbol": vi / syms_per_launch,
+                                     "busy_frac": (va / (ga / 8.0 * simds / 4.0)) if va and ga else None},
+                            "mfma_f16": {"insts_per_symbol": mi / syms_per_launch, "tflops": mi * 16 * 16 * 32 * 2 * per_s / 1e12,
+                                         "peak_tflops": PEAK_F16_MFMA_TFLOPS,
+                                         "frac": mi * 16 * 16 * 32 * 2 * per_s / 1e12 / PEAK_F16_MFMA_TFLOPS},
+                            "note": "issued work per pipe, from rocprofv3 PMC counts of this kernel on these sources "
+                                    "(profiles/hbm_traffic.json): valu.busy_frac = SQ_ACTIVE_INST_VALU quad-cycles over the "
+                                    "launch's SIMD quad-cycles (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / 4) as profiled; "
+                                    "mfma_f16 = v_mfma_f32_16x16x32_f16 flop at this run's launch rate against the dense "
+                                    "f16 matrix peak"}
             except Exception:
-                traffic = None
+                traffic, pipes = None, None
         out = {
             "metric": "OFDM symbols/sec (whole node) + BER vs reference, N=256 16-QAM",
             "value": total_syms / dt, "unit": "OFDM symbols/s", "n_gpus": world, "steps": a.steps,
@@ -196,7 +215,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "wofdm_frames_kernel<256,4,%d,false,false,0>" % plan.kernel_id()[0],
-                         "kernel_ms_avg": avg_ms,
+                         "kernel_ms_avg": avg_ms, "pipes": pipes,
                          "flop_per_symbol": fs,
                          "note": "achieved = algorithmic fp32 flop (SURVEY.md 8d F_sym x symbols) / kernel time, "
                                  "against the fp32 vector peak 157.3 TFLOP/s (= the fp32 MFMA dense peak). VALU issue "

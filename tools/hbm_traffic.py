@@ -25,6 +25,10 @@ json.dump({
     "workload": "bench.py default (C2), one launch = 12e6 OFDM symbols",
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
     "bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+    # per-pipe counters of the same launch, for bench.py's roofline.pipes (issued work, not algorithmic work)
+    "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"), "mfma_insts_per_launch": vals.get("SQ_INSTS_MFMA"),
+    "valu_active_quadcycles_per_launch": vals.get("SQ_ACTIVE_INST_VALU"),
+    "gui_active_cycles_per_launch": vals.get("GRBM_GUI_ACTIVE"),
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); "
            "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction of "
            "MI355X_MICROARCH.md.  The accesses here are scalar/dword constants and 8-byte atomics, which "

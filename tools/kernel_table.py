@@ -1,47 +1,45 @@
 #!/usr/bin/env python3
-"""Developer tool (build container): registers / spills / scratch of EVERY instantiation of the frame
-kernel, from `hipcc -S` of all 15 translation units.
+"""Developer tool (build container): registers / spills / scratch of EVERY instantiation of the frame kernel, read
+from the metadata notes of the BUILT library (what ships, per-translation-unit compiler flags included).
 
-    python tools/kernel_table.py > profiles/r02_kernel_table.json
+    python tools/kernel_table.py > profiles/r03_kernel_table.json
 
 tests/test_gpu_parity.py reads the committed table and runs the sharp-parity case for every production
-(non-instrumented) instantiation whose ScratchSize is not zero."""
+(non-instrumented) instantiation whose ScratchSize is not zero; tests/test_code_layout.py checks that the table still
+describes the built library."""
 import json
 import os
 import re
 import subprocess
 import sys
 import tempfile
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "w-ofdm-optimization_amd", "csrc", "wofdm_kernel.hip")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 FIELDS = ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")
 
 
-def one(nk):
-    n, k = nk
-    out = os.path.join(tempfile.mkdtemp(), "k.s")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                    "-fno-slp-vectorize", "-DWOFDM_TU_N=%d" % n, "-DWOFDM_TU_K=%d" % k, "-S",
-                    "--cuda-device-only", "-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
-    rows, cur = [], None
-    for l in open(out):
-        m = re.match(r"\s+\.name:\s+(\S+)", l)
-        if m:
-            t = re.search(r"wofdm_frames_kernelILi(\d+)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)", m.group(1))
-            cur = dict(zip(("n_fft", "k", "layout", "inject", "dump", "var"), map(int, t.groups()))) if t else None
-            if cur:
-                rows.append(cur)
-        m = re.match(r"\s+\.(\w+):\s+(\d+)", l)
-        if m and cur is not None and m.group(1) in FIELDS:
-            cur[m.group(1)] = int(m.group(2))
+def table(lib):
+    import test_code_layout as T
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in T._code_objects(lib, tmp):
+            notes = subprocess.run([os.path.join(T.LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
+                                   check=True).stdout
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk)
+                t = name and re.search(r"wofdm_frames_kernelILi(\d+)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)", name.group(1))
+                if not t:
+                    continue
+                row = dict(zip(("n_fft", "k", "layout", "inject", "dump", "var"), map(int, t.groups())))
+                for f in FIELDS:
+                    row[f] = int(re.search(r"\." + f + r":\s+(\d+)", blk).group(1))
+                rows.append(row)
+    rows.sort(key=lambda r: (r["n_fft"], r["k"], r["layout"], r["var"], r["inject"], r["dump"]))
     return rows
 
 
 if __name__ == "__main__":
-    nks = [(n, k) for n in (64, 128, 256, 512, 1024) for k in (2, 4, 6)]
-    with ThreadPoolExecutor(6) as ex:
-        rows = [r for part in ex.map(one, nks) for r in part]
-    rows.sort(key=lambda r: (r["n_fft"], r["k"], r["layout"], r["var"], r["inject"], r["dump"]))
-    json.dump({"source": "hipcc -S, ROCm 7.2, gfx950; tools/kernel_table.py", "kernels": rows}, sys.stdout, indent=0)
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "w-ofdm-optimization_amd", "libwofdm_hip.so")
+    json.dump({"source": "metadata notes of libwofdm_hip.so (hipcc, ROCm 7.2, gfx950); tools/kernel_table.py",
+               "kernels": table(lib)}, sys.stdout, indent=0)

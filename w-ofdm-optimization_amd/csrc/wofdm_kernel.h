@@ -19,8 +19,9 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   tw    float2[N]          twiddles exp(-2 pi i m / N)
 //   g     float2[N]          pilot equaliser X0/Y0
 //   sums  float [2][32]      per-wave signal / noise power partials, double-buffered by frame parity
-//   flags int   [32]         [w] = last loop iteration whose phase A wave w has finished,
-//                            [16] = last iteration whose pilot equaliser G is published
+//   flags int   [64]         [w] = last loop iteration whose phase A wave w has finished,
+//                            [16] = last iteration whose pilot equaliser G is published, [20] = a wave gave up waiting,
+//                            [32 + w] = (Tx-mask variants) last iteration whose masked symbol wave w has written to its row
 //   wtx   float [N + CPCS]   Tx window / N      (needs cp + cs <= CPCS_MAX = 128; 64 at N = 1024,
 //                            where the frame buffer leaves no room for more anyway)
 //   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)
@@ -33,7 +34,7 @@ template <int N> struct wofdm_lds {
     static constexpr int off_g = off_tw + 8 * N;
     static constexpr int off_sums = off_g + 8 * N;
     static constexpr int off_flags = off_sums + 4 * 64;
-    static constexpr int off_wtx = off_flags + 4 * 32;
+    static constexpr int off_wtx = off_flags + 4 * 64;
     static constexpr int off_wrx = off_wtx + 4 * (N + CPCS_MAX);
     static constexpr int off_lut = off_wrx + 4 * (N + TAILRX_MAX);
     static constexpr int off_fbuf = off_lut + 8 * 64;
@@ -142,7 +143,7 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 }
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 32 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
     return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
 }

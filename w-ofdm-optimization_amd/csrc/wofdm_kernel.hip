@@ -121,9 +121,13 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
 {
     const h2 h = __builtin_convertvector(y, h2);                       // v_cvt_pk_f16_f32 (RNE)
-    const h2 l = __builtin_convertvector(y - __builtin_convertvector(h, v2f), h2);
     hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
+    // lo = f16(y - float(hi)), one mixed-precision fma per half (the difference is exact in fp32, rounded once):
+    // three instructions per sample instead of five (two converts back, a packed subtract, a packed convert)
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(y.x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(y.y));
+    lo = l;
 }
 __device__ __forceinline__ v2f join_h(uint32_t hi, uint32_t lo)
 {
@@ -823,6 +827,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
     constexpr bool RELAX = WOFDM_RELAXED_SYNC && !DUMP && VAR < 2;
+    // The Tx-mask variants (one symbol per wave) have one more hand-over: symbol s adds the second half of its
+    // masked output onto the row of symbol s + 1 (dft_rc_filt's overlap, m:411-415).  Flags as well: [32 + s] = "my own
+    // row holds my masked symbol", then [s] = "... and my spill is on my successor's row".  Phase B of wave w needs its
+    // own row (complete once w - 1 has spilled: flag w - 1) and the end of its predecessor's (complete once w - 2
+    // has: flag w - 2).
+    constexpr bool RELAXM = WOFDM_RELAXED_SYNC && !DUMP && VAR >= 2;
+    constexpr bool RELAXF = RELAX || RELAXM;         // flags instead of barriers 1 and 3
     static_assert(!(TXMASK || TXFFT) || SPW == 1, "the Tx mask stage runs one symbol per wave");
     constexpr int LT = WOFDM_LT;
     constexpr int BPL = geo<N>::BPL, NQ = geo<N>::NQ;
@@ -892,7 +903,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
     DELAY_AT(11);
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
-    if (tid < 32) flags[tid] = 0;
+    if (tid < 64) flags[tid] = 0;
     int iter = 0;                                  // frames this workgroup has started
     if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
     else fill_twiddles<N>(tw, tid, (int)blockDim.x);
@@ -1385,7 +1396,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         else tailb[s * TS + (n - B)] = y[0][q][r];
                     }
                 }
-            __syncthreads();
+            if constexpr (RELAXM) {
+                wave_sync();
+                post_flag(&flags[32 + wv], iter, lane);
+                if (!last) wait_flag(&flags[32 + wv + 1], iter, &flags[20]);
+            } else {
+                __syncthreads();
+            }
             if (!last) {
                 const bool nlast = s + 1 == S - 1;
                 v2f *fn = fb + B;
@@ -1449,7 +1466,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     else tailb[s * TS + (n - B)] = y[i];
                 }
             }
-            __syncthreads();
+            if constexpr (RELAXM) {
+                wave_sync();
+                post_flag(&flags[32 + wv], iter, lane);
+                if (!last) wait_flag(&flags[32 + wv + 1], iter, &flags[20]);
+            } else {
+                __syncthreads();
+            }
             // next symbol's row += y[P..2P-1)
             if (!last) {
                 const bool nlast = s + 1 == S - 1;
@@ -1467,12 +1490,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         DELAY_AT(2);
         STAMP(0);
-        if constexpr (RELAX) {
+        if constexpr (RELAXF) {
             // ---- "barrier" 1: publish "my symbols are written"; phase B waits for the
             // predecessor wave only (its last L-1 samples and its fall tail)
             wave_sync();
             if (!(WOFDM_FAULT_SKIP_FLAG && wv == 1 && iter == 3)) post_flag(&flags[wv], iter, lane);
             if (wv > 0) wait_flag(&flags[wv - 1], iter, &flags[20]);
+            if constexpr (RELAXM) {
+                if (wv > 1) wait_flag(&flags[wv - 2], iter, &flags[20]);
+            }
         } else {
             __syncthreads();                                                 // ---- barrier 1
         }
@@ -1785,9 +1811,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int idle = 64 - nmain;
         const int ntc = (tail_total + RB - 1) / RB;
         const bool tail_in_idle = idle * W >= ntc;
-        if constexpr (RELAX) {
-            // waves that carry trailing samples of the frame read behind the last symbol
-            if (tail_in_idle && wv != W - 1 && (W - 1 - wv) * idle < ntc) wait_flag(&flags[W - 1], iter, &flags[20]);
+        if constexpr (RELAXF) {
+            // waves that carry trailing samples of the frame read behind the last symbol (whose row, in the Tx-mask
+            // variants, is complete once its predecessor has spilled onto it)
+            if (tail_in_idle && wv != W - 1 && (W - 1 - wv) * idle < ntc) {
+                wait_flag(&flags[W - 1], iter, &flags[20]);
+                if constexpr (RELAXM) {
+                    if (W > 1) wait_flag(&flags[W - 2], iter, &flags[20]);
+                }
+            }
         }
         is_main = lane < nmain;
         if (is_main) {
@@ -1852,8 +1884,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (!tail_in_idle && tail_total > 0 && wv == 0) {
             // no idle lanes: the trailing samples (they only feed the power sums) go to wave 0, the
             // wave that reaches barrier 2 first; it needs the last wave's symbols for them
-            if constexpr (RELAX) {
+            if constexpr (RELAXF) {
                 if (W > 1) wait_flag(&flags[W - 1], iter, &flags[20]);
+                if constexpr (RELAXM) {
+                    if (W > 2) wait_flag(&flags[W - 2], iter, &flags[20]);
+                }
             }
             for (int t = lane; t < tail_total; t += 64) {
                 const int j = S * B + t;
@@ -2059,7 +2094,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const float inv = __builtin_amdgcn_rcpf(y0.x * y0.x + y0.y * y0.y);
                 G[n] = cmul_conj(x0, y0) * inv;
             }
-            if constexpr (RELAX) {
+            if constexpr (RELAXF) {
                 wave_sync();
                 post_flag(&flags[16], iter, lane);
             }
@@ -2080,7 +2115,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
-            if constexpr (RELAX) {
+            if constexpr (RELAXF) {
                 wave_sync();
                 post_flag(&flags[16], iter, lane);
             }
@@ -2088,7 +2123,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         DELAY_AT(8);
         STAMP(4);
-        if constexpr (RELAX) {
+        if constexpr (RELAXF) {
             if (wv != 0) wait_flag(&flags[16], iter, &flags[20]);                        // ---- "barrier" 3
         } else {
             __syncthreads();                                                 // ---- barrier 3
@@ -2168,7 +2203,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (++fidx == F) { fidx = 0; next_cell(); }
     }
     if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
-    if constexpr (RELAX && WOFDM_CHECKED_SYNC) {
+    if constexpr (RELAXF && WOFDM_CHECKED_SYNC) {
         __syncthreads();
         if (tid == 0 && flags[20] != 0) atomicOr(p.status, 1u);   // host: results not to be used
     }
