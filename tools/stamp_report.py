@@ -25,15 +25,19 @@ frames = 62500 * 256 // n
 with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.complex64), snr) as plan:
     info = plan.info()
     grid, waves = info["workgroups"], info["waves_per_workgroup"]
-    buf = torch.zeros(4 * 12 + grid * 16 * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4 * 12 + grid * 16 * 16, dtype=torch.int64, device="cuda")
     ms = plan.launch_timed(0, frames, buf)
     torch.cuda.synchronize()
-    st_ = buf[48:].cpu().numpy().reshape(grid, 16, 8)[:, :waves, :].astype(np.float64)
-names = ["A bits/QAM/IFFT/tx", "wait barrier 1", "B noise/FIR/power", "wait barrier 2",
-         "C r/Rx/FFT/pilot", "wait barrier 3", "D equalise/demap", "loop control"]
+    st_ = buf[48:].cpu().numpy().reshape(grid, 16, 16)[:, :waves, :].astype(np.float64)
+names = ["A4 Tx write (+ mask)", "wait barrier 1", "B3 trailing tile, power sums", "wait barrier 2",
+         "C4 pilot estimate", "wait barrier 3", "D equalise/demap", "loop control",
+         "A1 Philox data bits", "A2 labels, QAM", "A3 IFFT", "B1 overlap-add, operands", "B2 tiles: FIR + noise",
+         "C1 gain, r = c + g n", "C2 Rx window loads", "C3 FFT"]
+order = [7, 8, 9, 10, 0, 1, 11, 12, 2, 3, 13, 14, 15, 4, 5, 6]
 tot = st_.sum(axis=2)
 print("N=%d k=%d: %.2f ms, %d workgroups x %d waves; mean cycles per wave %.3e" % (n, k, ms, grid, waves, tot.mean()))
-for i, nm in enumerate(names):
+for i in order:
+    nm = names[i]
     sh = st_[:, :, i] / tot
     print("  %-22s all waves %5.1f %%   wave 0 %5.1f %%   last wave %5.1f %%"
           % (nm, 100 * sh.mean(), 100 * sh[:, 0].mean(), 100 * sh[:, -1].mean()))

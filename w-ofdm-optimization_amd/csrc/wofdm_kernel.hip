@@ -76,9 +76,11 @@ namespace {
         stamp_t = now_;                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                     \
     } while (0)
+#define STAMPF(slot) STAMP(slot)          /* finer marks inside the phases (slots 8..15) */
 #else
 // (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
+#define STAMPF(slot) do { } while (0)
 #endif
 
 // The FIR's six MFMAs of a tile (fir_mma) are ONE asm block that starts on a 64-byte boundary: its 60 bytes sit in one
@@ -723,6 +725,19 @@ __device__ __forceinline__ float wave_sum(float x)
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// every lane its 16-lane row's sum (four DPP steps)
+__device__ __forceinline__ float row_sum(float x)
+{
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});
+    x += dpp(x, std::integral_constant<int, 0x4E>{});
+    x += dpp(x, std::integral_constant<int, 0x141>{});
+    x += dpp(x, std::integral_constant<int, 0x140>{});
+    return x;
+}
 // (same scheme for the error counters: no lane-index vectors, which the compiler would hoist out of
 // the frame loop and spill)
 __device__ __forceinline__ unsigned wave_sum_u(unsigned x)
@@ -904,6 +919,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     DELAY_AT(11);
     for (int i = tid; i < gm[WOFDM_G_FBUF]; i += blockDim.x) fbuf[i] = mk(0.f, 0.f);
     if (tid < 64) flags[tid] = 0;
+    if (tid < 64) sums[tid] = 0.f;                 // (waves a short frame does not have leave their partial sums at zero)
     int iter = 0;                                  // frames this workgroup has started
     if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
     else fill_twiddles<N>(tw, tid, (int)blockDim.x);
@@ -999,7 +1015,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     };
 
 #ifdef WOFDM_STAMP
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     for (; n_items != 0; --n_items) {
@@ -1122,6 +1138,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             wave_sync();
         }
+        STAMPF(8);
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const int s = sym_of(u);
@@ -1169,8 +1186,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
+        STAMPF(9);
         if constexpr (QW) fft_qw<+1>(v, row(usq), tw, llq);
         else fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);     // v = N x[t]
+        STAMPF(10);
 
         // add_redundancy (m:419-439) x diag(windowTx) (m:375): x[t] lands at i = t+mu, and at
         // t+mu-N (prefix) / t+mu+N (suffix) when those exist.  i >= B is the fall tail that
@@ -1730,8 +1749,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         };
         DELAY_AT(4);
+        STAMPF(11);
         if (all_full) tiles(std::true_type{});
         else tiles(std::false_type{});
+        STAMPF(12);
         DELAY_AT(5);
         const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
         if (tail_total > 0 && wv == 0) {
@@ -1926,6 +1947,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         }
         DELAY_AT(6);
+        // Phase C's structure lengths are requested HERE, in front of the barrier: the scalar loads' latency runs under
+        // the wait instead of opening the phase, where the wave has nothing else to issue (a stamped build showed the
+        // start of phase C -- these loads, then a loop of dependent LDS reads over the waves' partial sums -- taking
+        // 8.6 % of a wave's time for two dozen instructions).
+        int goffc_ = 0;
+        asm volatile("" : "+s"(goffc_));
+        const int *__restrict__ gqc = gm + goffc_;
+        const int cS = gqc[WOFDM_G_S], cB = gqc[WOFDM_G_B], cDelta = gqc[WOFDM_G_DELTA], cGam = gqc[WOFDM_G_GAMMA];
+        const int cPlen = FIRQ ? gqc[WOFDM_G_FBUF] : 0;
         STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
         STAMP(3);
@@ -1934,11 +1964,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         {
-        GEO_PHASE();
-        const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], delta = gq[WOFDM_G_DELTA];
-        const int gam = gq[WOFDM_G_GAMMA], kap = gq[WOFDM_G_KAPPA];
-        const int W = S / SPW;
-        const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
+        const int S = cS, B = cB, delta = cDelta, gam = cGam, kap = 0;
+        const int plen = cPlen;
+        (void)S;
         v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
         auto row = [&](int u) -> v2f * {
             if constexpr (FIRQ)
@@ -1946,8 +1974,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             else
                 return fbw + u * B;
         };
-        float Ps = 0.f, Pn = 0.f;
-        for (int w2 = 0; w2 < W; ++w2) { Ps += sums_it[w2]; Pn += sums_it[16 + w2]; }
+        // total powers: ONE LDS round trip -- lane l reads partial sum l & 31 (signal powers of the waves in 0..15, noise
+        // powers in 16..31; entries of waves the frame does not have stay zero), rows 0 and 1 of the wave add up
+        float Ps, Pn;
+        {
+            const float part = row_sum(sums_it[lane & 31]);
+            Ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
+            Pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+        }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
 #ifdef WOFDM_AUDIT
         aud_g = g; aud_ps = Ps; aud_pn = Pn;
@@ -1998,6 +2032,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (DUMP && p.dump.gain && tid == 0)
             p.dump.gain[0] = g * p.dump_unscale_rx * ((FIRM && !INJECT) ? 1.0f / WOFDM_NOISE_UNSCALE : 1.0f);
         wave_sync();
+        STAMPF(13);
 
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
@@ -2052,8 +2087,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
+        STAMPF(14);
         if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
         else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
+        STAMPF(15);
 
         if (DUMP && p.dump.Y) {
 #pragma unroll
@@ -2210,8 +2247,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #ifdef WOFDM_STAMP
     if (lane0 == 0) {
         unsigned long long *dst = p.counts + 4 * (size_t)(p.first_cell + p.n_cells)
-                                  + ((size_t)blockIdx.x * 16 + wv) * 8;
-        for (int i = 0; i < 8; ++i) dst[i] = stamp_acc[i];
+                                  + ((size_t)blockIdx.x * 16 + wv) * 16;
+        for (int i = 0; i < 16; ++i) dst[i] = stamp_acc[i];
     }
 #endif
 }
