@@ -133,7 +133,8 @@ def test_one_frame_stage_by_stage(channels, system, n_fft, cp, k, matlab, inject
 def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
     """conv(channel, tx) (main_BER_calculation.m:260) of one injected frame against the fp64 oracle: the matrix-pipe form
     (three f16 x f16 MFMA terms of hi/lo halves, fp32 accumulation: 22-bit operands, h_lo x_lo dropped) and the fp32
-    VALU form of the same kernels (plan option fir_valu).  Error over the frame's rms; bound 1e-6 for either."""
+    VALU form of the same kernels (plan option fir_valu).  Error over the frame's rms; bounds 2e-6 (max) and 3e-7 (rms, FIR alone) for either -- measured 7e-7 / 1.3e-7 (matrix pipe) against
+    7e-7 / 1.1e-7 (VALU): both sit at the fp32 rounding floor of the stage dumps."""
     S, seed, frame, cell = 16, 3, 77, 1
     st = W.make_structure(system, n_fft, cp)
     w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
@@ -153,10 +154,18 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
             assert (layout in (6, 7, 8)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e = np.abs(gd["conv"] - od["conv"])
-        err[name] = (layout, float(e.max() / rms), float(np.sqrt(np.mean(e ** 2)) / rms))
+        # ... and the FIR alone: against the fp64 convolution of the kernel's OWN transmitted frame (the chain's error
+        # above is mostly the fp32 IFFT in front of it)
+        own = np.convolve(h[1].astype(np.complex128), gd["tx"].astype(np.complex128))
+        f = np.abs(gd["conv"] - own)
+        err[name] = (layout, float(e.max() / rms), float(np.sqrt(np.mean(e ** 2)) / rms), float(f.max() / rms),
+                     float(np.sqrt(np.mean(f ** 2)) / rms))
     print("\nconv vs fp64, %s N=%d cp=%d: " % (system, n_fft, cp)
-          + "; ".join("%s (layout %d): max %.2e rms %.2e of the frame's rms" % ((n,) + err[n]) for n in err))
-    assert err["matrix pipe"][1] <= 1e-6 and err["valu"][1] <= 1e-6, err
+          + "; ".join("%s (layout %d): whole chain max %.2e rms %.2e, FIR alone max %.2e rms %.2e of the frame's rms"
+                      % ((n,) + err[n]) for n in err))
+    assert err["matrix pipe"][1] <= 2e-6 and err["valu"][1] <= 2e-6, err
+    assert err["matrix pipe"][3] <= 2e-6 and err["valu"][3] <= 2e-6, err
+    assert err["matrix pipe"][4] <= 3e-7 and err["valu"][4] <= 3e-7, err        # rms: both at the fp32 rounding floor of the dumps
 
 
 @pytest.mark.parametrize("system,n_fft,cp,k,opts", [("wtx", 256, 32, 4, {}), ("CPW", 256, 32, 6, {}), ("WOLA", 512, 32, 4, {}),
@@ -646,6 +655,26 @@ def test_first_launch_in_a_fresh_process(n_fft, k):
     n_kernels, n_bad = int(last[1]), int(last[2])
     assert n_kernels >= (8 if n_fft >= 512 else 6), r.stdout
     assert n_bad == 0, r.stdout
+
+
+def test_back_to_back_mfma_chains_leave_the_neighbours_alone():
+    """The assumption the FIR's chain rests on, checked on THIS GPU (tools/ubench/mfma_stall_victim.hip --quick): six
+    in-place v_mfma_f32_16x16x32_f16 issued back to back -- up to 6 wait states between two of them -- never disturb packed
+    op_sel arithmetic of the SIMD's other waves, even when those are the older (preferred) waves; 16 wait states between
+    the fifth and the sixth do (printed, not asserted: that part documents the hazard)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "native", "mfma_stall_victim")
+    assert os.path.exists(exe), "make -C tests/native"
+    r = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [dict(kv.split("=") for kv in l.split()[1:]) for l in r.stdout.split("\n") if l.startswith("RESULT")]
+    assert len(rows) == 5, r.stdout
+    for row in rows:
+        assert int(row["chains_bad"]) == 0, row                       # the chain's own sums are never what breaks
+        if int(row["gap"]) <= 6:
+            assert int(row["bystanders_bad"]) == 0, row
+        else:
+            print("\n16 wait states inside the chain: %s wrong bystander values" % row["bystanders_bad"])
 
 
 def test_lds_poison_tool_works():

@@ -48,8 +48,9 @@ def classify(op):
 
 def compile_tu(n, k, extra):
     out = os.path.join(tempfile.mkdtemp(), "k.s")
+    sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if n == "512" else []      # (the Makefile's SCHED_512)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                    "-fno-slp-vectorize", "-DWOFDM_TU_N=" + n, "-DWOFDM_TU_K=" + k, *extra, "-S",
+                    "-fno-slp-vectorize", *sched, "-DWOFDM_TU_N=" + n, "-DWOFDM_TU_K=" + k, *extra, "-S",
                     "--cuda-device-only", "-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
     return open(out).read().split("\n")
 

@@ -133,16 +133,18 @@ template <int KIND, int POS, int G, int PK, int FORM = 0> __global__ void __laun
     }
 }
 
+static bool g_quick = false;
 template <int KIND, int POS, int G, int PK, int FORM = 0> void run(const char *what, unsigned chain_mask = 0x0FFFu, unsigned by_mask = 0xF000u)
 {
     unsigned *d;
     hipMalloc(&d, 64 * sizeof(unsigned));
     hipMemset(d, 0, 64 * sizeof(unsigned));
-    const int iters = 20000;
+    const int iters = g_quick ? 4000 : 20000;
     hipLaunchKernelGGL((k<KIND, POS, G, PK, FORM>), dim3(256), dim3(1024), 0, 0, d, iters, chain_mask, by_mask);
     hipDeviceSynchronize();
     std::vector<unsigned> h(64);
     hipMemcpy(h.data(), d, 64 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (g_quick) printf("RESULT gap=%d pos=%d kind=%d bystander=%d chains_bad=%u bystanders_bad=%u\n", G, POS, KIND, PK, h[0], h[1]);
     printf("%-44s chains' wrong sums %8u of %.2e; bystanders' wrong values %8u of %.2e (by lane row: %u %u %u %u)\n", what, h[0],
            256.0 * __builtin_popcount(chain_mask) * 64 * 4 * iters, h[1], 256.0 * __builtin_popcount(by_mask) * 64 * 16 * iters, h[2], h[3], h[4], h[5]);
     static bool first = true;
@@ -155,8 +157,19 @@ template <int KIND, int POS, int G, int PK, int FORM = 0> void run(const char *w
     hipFree(d);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 'q') {
+        // --quick (tests/test_gpu_parity.py::test_back_to_back_mfma_chains_leave_the_neighbours_alone): the shipped form of the
+        // chain under the least favourable arbitration, and the gap that is known to break the neighbours
+        g_quick = true;
+        run<0, 0, 0, 3>("no gap, bystanders 12..15");
+        run<0, 0, 0, 3>("no gap, bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+        run<0, 0, 0, 7>("no gap, pk_fma bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+        run<0, 5, 6, 3>("6 ws behind MFMA 5, bystanders 0..11, chains 12..15", 0xF000u, 0x0FFFu);
+        run<0, 5, 16, 3>("16 wait states behind MFMA 5");
+        return 0;
+    }
     // 1) gap length behind the fifth MFMA; bystanders: v_pk_add_f32 with the kernel's add_mi modifiers (op_sel + neg)
     run<0, 0, 0, 3>("no gap, swizzled pk_add");
     run<0, 5, 1, 3>("1 wait state behind MFMA 5");

@@ -114,8 +114,9 @@ __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 // Matrix-pipe FIR (layouts 6, 7, 8): samples travel through LDS as two packed-f16 words, y = hi + lo with both
 // halves rounded to nearest: two 11-bit significands, |y - hi - lo| <= 2^-22 |y|.  Three f16 MFMA terms
 // (h_hi x_hi + h_hi x_lo + h_lo x_hi, fp32 accumulation) drop h_lo x_lo, another 2^-22: a product is good to about
-// 2^-21, four times coarser than an fp32 product -- measured on whole frames against fp64 arithmetic: conv off by
-// 2e-7 of its largest sample (tests/test_gpu_parity.py::test_fir_precision_matrix_pipe_vs_valu).
+// 2^-21, four times coarser than an fp32 product -- on whole frames, against fp64 arithmetic, conv is off by 1.3e-7
+// (rms) of the frame's rms, the fp32 VALU form by 1.1e-7: both at the rounding floor of the fp32 stages around them
+// (tests/test_gpu_parity.py::test_fir_precision_matrix_pipe_vs_valu).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
