@@ -58,6 +58,11 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
+// N = 1024: tiles whose unit noise stays in registers instead of being parked in the HBM scratch row (see phase B)
+#ifndef WOFDM_NOISE_KEEP_TILES
+#define WOFDM_NOISE_KEEP_TILES 6
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -1693,7 +1698,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                          : "v"(A[1]), "v"(A[3]), "v"(A[0]), "v"(A[2]), "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1));
             return d;
         };
-        f4 *nscr = nullptr;                         // large DFTs: the unit noise is parked in HBM scratch
+        // (large DFTs: the unit noise of the tiles from NKEEP on is parked in HBM scratch; the first NKEEP tiles' stays in
+        // registers -- as many as the 128-VGPR budget allows: what is parked has to FIT the XCD's 4 MB of L2 together with
+        // the other 31 workgroups' rows, or every access of the cyclic write / read-back pattern misses; with all nine tiles
+        // parked (4.7 MB per XCD) the N = 1024 kernel drew 250 W more, ran at the 1 400 W cap and 5 % slower)
+        constexpr int NKEEP = WOFDM_NOISE_KEEP_TILES;
+        f4 *nscr = nullptr;
         if constexpr (RENOISE)
             nscr = reinterpret_cast<f4 *>(p.noise_scratch) + ((size_t)blockIdx.x * 16 + wv) * (NT * 64) + lane;
         // (two instantiations of the tile loop: with every lane of every tile in use -- C2 -- the
@@ -1721,7 +1731,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             noise_pair(jw + jr, valid, valid, n0, n1);
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
-            if constexpr (RENOISE) {
+            if (RENOISE && (INJECT || G >= NKEEP)) {
                 if (!INJECT) nscr[64 * G] = (f4){n0.x, n0.y, n1.x, n1.y};
             } else {
                 nz[2 * G] = n0; nz[2 * G + 1] = n1;
@@ -1798,7 +1808,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     bool valid = 128 * G + jl < LW;
                     if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                     noise_pair(jw + 128 * G + jl, valid, valid, nz[2 * G], nz[2 * G + 1]);
-                } else {
+                } else if (G >= NKEEP) {
                     const f4 t = nscr[64 * G];
                     nz[2 * G] = mk(t.x, t.y); nz[2 * G + 1] = mk(t.z, t.w);
                 }
