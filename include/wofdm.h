@@ -157,8 +157,8 @@ int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
 
 /* Which instantiation of the frame kernel the plan launches: {layout id, variant}.  Layout: 1, 2 =
  * one / two symbols per wave with the FIR on the VALU; 4, 5 = four symbols per wave (N = 256), FIR on
- * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 8 = one symbol per wave (N >= 512), FIR on
- * the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
+ * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 10, 11 = 6, 7 with both 256-point transforms on
+ * the matrix pipe as well; 8 = one symbol per wave (N >= 512), FIR on the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
  * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
 int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
 
@@ -169,10 +169,14 @@ int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
  *                            (round-1 kernels) instead of the matrix pipe; 0 = default
  *   WOFDM_OPT_MAX_SPW        at most 1, 2 or 4 OFDM symbols per wavefront; 0 = default (the most that fits)
  *   WOFDM_OPT_TXMASK_DIRECT  1 = the Tx mask (wofdm_plan_set_tx_mask) always as a direct-form convolution instead
- *                            of fast convolution where that fits; 0 = default */
+ *                            of fast convolution where that fits; 0 = default
+ *   WOFDM_OPT_DFT_VALU       1 = the 256-point IDFT / DFT (dftmtx, main_BER_calculation.m:306, 370) as in-register radix-16
+ *                            stages on the VALU (layouts 6, 7) instead of split-f16 products on the matrix pipe (layouts
+ *                            10, 11); 0 = default */
 #define WOFDM_OPT_FIR_VALU       0
 #define WOFDM_OPT_MAX_SPW        1
 #define WOFDM_OPT_TXMASK_DIRECT  2
+#define WOFDM_OPT_DFT_VALU       3
 int wofdm_plan_set_option(wofdm_plan *plan, int32_t option, int32_t value);
 
 /* One-shot, host pointers in / host counters out (synchronous):

@@ -47,9 +47,9 @@ def _expected_layout(st, n_fft, S):
     B = st.stride
     if n_fft == 256 and S % 4 == 0 and B >= n_fft:
         if 4 * B <= 128 * 9:
-            return 6
+            return 10
         if 4 * B <= 128 * 10:
-            return 7
+            return 11
     if n_fft == 256 and S % 4 == 0:
         if 4 * B <= 64 * 18:
             return 4
@@ -151,7 +151,7 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("fir_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (6, 7, 8)) == (valu == 0), layout
+            assert (layout in (6, 7, 8, 10, 11)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e = np.abs(gd["conv"] - od["conv"])
         # ... and the FIR alone: against the fp64 convolution of the kernel's OWN transmitted frame (the chain's error
@@ -537,8 +537,10 @@ def _geometry_for(n_fft, layout, var):
     if layout in (4, 5):
         env["fir_valu"] = 1
         return ("wtx" if layout == 4 else "CPW"), 32, 16, env        # strides 288 / 293
-    if layout in (6, 7):
-        return "wtx", (32 if layout == 6 else 48), 16, env              # strides 288 / 304
+    if layout in (6, 7, 10, 11):
+        if layout in (6, 7):
+            env["dft_valu"] = 1
+        return "wtx", (32 if layout in (6, 10) else 48), 16, env        # strides 288 / 304
     assert layout == 8
     return "WOLA", 32, 16, env
 
@@ -623,7 +625,7 @@ ch = np.load(%r)["h"]
 st = W.make_structure("wtx", 256, 32)
 cfg = W.make_cfg(st, 4, 16, 21, 1, 2, 1, seed=2)
 with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.complex64), [10.0, 20.0]) as plan:
-    assert plan.kernel_id() == (6, 0)
+    assert plan.kernel_id() == (10, 0)
     ok = plan.run(0, 2)                      # two frames per workgroup at most: the fault is not reached
     try:
         plan.run(0, 20000)

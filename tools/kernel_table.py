@@ -28,7 +28,7 @@ def table(lib):
                                    check=True).stdout
             for blk in notes.split("- .agpr_count:")[1:]:
                 name = re.search(r"\.name:\s+(\S+)", blk)
-                t = name and re.search(r"wofdm_frames_kernelILi(\d+)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)", name.group(1))
+                t = name and re.search(r"wofdm_frames_kernelILi(\d+)ELi(\d)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)", name.group(1))
                 if not t:
                     continue
                 row = dict(zip(("n_fft", "k", "layout", "inject", "dump", "var"), map(int, t.groups())))

@@ -19,7 +19,7 @@ WOFDM_OK = 0
 ERRORS = {-1: "WOFDM_E_INVALID", -2: "WOFDM_E_UNSUPPORTED", -3: "WOFDM_E_HIP", -4: "WOFDM_E_NOMEM"}
 MAX_TAPS = 21
 #: wofdm_plan_set_option: diagnostic kernel choice (include/wofdm.h)
-OPTIONS = {"fir_valu": 0, "max_spw": 1, "txmask_direct": 2}
+OPTIONS = {"fir_valu": 0, "max_spw": 1, "txmask_direct": 2, "dft_valu": 3}
 MAX_SYMS = 16
 
 #: every symbol include/wofdm.h declares (tests check the .so exports them all)

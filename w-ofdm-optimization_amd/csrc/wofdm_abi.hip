@@ -96,6 +96,7 @@ struct wofdm_plan {
     // wofdm_plan_set_option: diagnostic kernel choice
     bool force_direct_mask = false;    // WOFDM_OPT_TXMASK_DIRECT: never the FFT form
     bool fir_valu = false;             // WOFDM_OPT_FIR_VALU: FIR on the VALU in every layout
+    bool dft_valu = false;             // WOFDM_OPT_DFT_VALU: N = 256 transforms on the VALU (layouts 6, 7 instead of 10, 11)
     int max_spw = 0;                   // WOFDM_OPT_MAX_SPW: 0 = no cap
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
@@ -103,6 +104,8 @@ struct wofdm_plan {
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
     uint4 *d_fira = nullptr;           // [n_ch][4][64] Toeplitz operands of the matrix-pipe FIR (MFMA A layout)
     float firm_sx = 1.f, firm_sh = 1.f; // powers of two carried by the f16 samples / f16 taps there
+    uint4 *d_dftc = nullptr;           // [10][64] operands of the matrix-pipe 256-point transforms (build_dftc)
+    float *d_rxs = nullptr;            // [n_snr][n_ch] power of two that centres the received samples in the f16 range
 #ifdef WOFDM_AUDIT
     uint32_t *audit = nullptr;
     uint32_t audit_items = 0;
@@ -124,7 +127,7 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
-    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm);
+    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm, !pl->dft_valu);
     if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
@@ -177,6 +180,8 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     }
     kp.noise_scratch = pl->d_nscr;
     kp.status = pl->d_status;
+    kp.dftc = pl->d_dftc;
+    kp.rx_scale = pl->d_rxs;
     kp.items_q = total_items / grid;
     kp.items_r = total_items % grid;
     kp.lds_bytes = pl->base.lds_bytes;
@@ -301,6 +306,64 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
                 }
     std::vector<float> nlin(cfg->n_snr);
     for (int i = 0; i < cfg->n_snr; ++i) nlin[i] = (float)std::pow(10.0, -0.1 * (double)snr_db[i]);
+    // Matrix-pipe 256-point transforms (wofdm_kernel.hip, mdft_fwd; layouts 10, 11): per lane (a = lane % 16, g = lane / 16)
+    // the operand rows of th^(x y), th = exp(-2 pi i / 16), as {Fr, -Fi} (real outputs) / {Fi, Fr} (imaginary outputs) over
+    // K = (index, re | im), split into f16 hi + lo:
+    //   rows 0..3  stage 1, B operand: column k1 = a, K slot (g, j) <-> n1 = g + 4 j          (re hi, re lo, im hi, im lo)
+    //   rows 4..7  stage 2, A operand: row a <-> k2 = a / 4 + 4 (a % 4), K slot (g, j) <-> n2 = 4 g + j
+    //   rows 8, 9  the inter-stage twiddles exp(-2 pi i (4 g + j) a / 256), j < 4: real parts, imaginary parts (fp32)
+    std::vector<uint32_t> dftc((size_t)10 * 64 * 4);
+    {
+        const double PI = 3.14159265358979323846;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int a = lane & 15, gq = lane >> 4;
+            for (int j = 0; j < 4; ++j) {
+                for (int st = 0; st < 2; ++st) {
+                    const int x = st == 0 ? gq + 4 * j : 4 * gq + j;         // contracted index of the K slot
+                    const int y = st == 0 ? a : (a >> 2) + 4 * (a & 3);      // output index of the lane
+                    const double ang = -2.0 * PI * (double)((x * y) & 15) / 16.0;
+                    double fr = std::cos(ang), fi = std::sin(ang);
+                    if (((x * y) & 3) == 0) {                                 // multiples of a quarter turn: exact 0, +-1
+                        fr = std::round(fr); fi = std::round(fi);
+                    }
+                    const double vals[2][2] = {{fr, -fi}, {fi, fr}};          // [re | im output][K = re | im input]
+                    for (int o = 0; o < 2; ++o) {
+                        uint32_t whi = 0, wlo = 0;
+                        for (int c = 0; c < 2; ++c) {
+                            const _Float16 vh = (_Float16)vals[o][c];
+                            const _Float16 vl = (_Float16)(vals[o][c] - (double)vh);
+                            uint16_t bh, bl;
+                            std::memcpy(&bh, &vh, 2); std::memcpy(&bl, &vl, 2);
+                            whi |= (uint32_t)bh << (16 * c);
+                            wlo |= (uint32_t)bl << (16 * c);
+                        }
+                        dftc[((size_t)(4 * st + 2 * o + 0) * 64 + lane) * 4 + j] = whi;
+                        dftc[((size_t)(4 * st + 2 * o + 1) * 64 + lane) * 4 + j] = wlo;
+                    }
+                }
+                const double ang = -2.0 * PI * (double)((4 * gq + j) * a) / 256.0;
+                const float twr = (float)std::cos(ang), twi = (float)std::sin(ang);
+                std::memcpy(&dftc[((size_t)8 * 64 + lane) * 4 + j], &twr, 4);
+                std::memcpy(&dftc[((size_t)9 * 64 + lane) * 4 + j], &twi, 4);
+            }
+        }
+    }
+    // received samples in kernel units: natural units (unit-power symbols, 1/N in the IDFT: rms 1/sqrt(N)) x firm_sx x firm_sh x
+    // |h|, plus noise; a power of two per (snr, channel) brings their rms to about 16 (everything behind is homogeneous
+    // in it: the equaliser divides by the pilot)
+    std::vector<float> rxs((size_t)cfg->n_snr * cfg->n_channels, 1.0f);
+    for (int i = 0; i < cfg->n_snr; ++i)
+        for (int c = 0; c < cfg->n_channels; ++c) {
+            double e = 0.0;
+            for (int l = 0; l < g.L; ++l) {
+                const double hr = h[2 * ((size_t)c * g.L + l)], hi = h[2 * ((size_t)c * g.L + l) + 1];
+                e += hr * hr + hi * hi;
+            }
+            const double rms = (double)pl->firm_sx * (double)pl->firm_sh * std::sqrt(e * (1.0 + (double)nlin[i]) / (double)g.N)
+                               * std::fmax(wmax, 1e-30);
+            if (rms > 0.0 && std::isfinite(rms))
+                rxs[(size_t)i * cfg->n_channels + c] = (float)std::exp2(std::round(4.0 - std::log2(rms)));
+        }
 
 #define PLAN_TRY(expr)                                                                        \
     do {                                                                                      \
@@ -322,6 +385,10 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     PLAN_TRY(hipMemcpy(pl->d_nlin, nlin.data(), nlin.size() * sizeof(float), hipMemcpyHostToDevice));
     PLAN_TRY(hipMalloc(&pl->d_fira, fira.size() * sizeof(_Float16)));
     PLAN_TRY(hipMemcpy(pl->d_fira, fira.data(), fira.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMalloc(&pl->d_dftc, dftc.size() * sizeof(uint32_t)));
+    PLAN_TRY(hipMemcpy(pl->d_dftc, dftc.data(), dftc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMalloc(&pl->d_rxs, rxs.size() * sizeof(float)));
+    PLAN_TRY(hipMemcpy(pl->d_rxs, rxs.data(), rxs.size() * sizeof(float), hipMemcpyHostToDevice));
     PLAN_TRY(hipEventCreate(&pl->ev0));
     PLAN_TRY(hipEventCreate(&pl->ev1));
 
@@ -375,6 +442,8 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
     if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->d_fira) (void)hipFree(pl->d_fira);
+    if (pl->d_dftc) (void)hipFree(pl->d_dftc);
+    if (pl->d_rxs) (void)hipFree(pl->d_rxs);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     delete pl;
@@ -484,7 +553,7 @@ int wofdm_plan_set_option(wofdm_plan *pl, int32_t option, int32_t value)
     if (!pl) return fail(WOFDM_E_INVALID, "plan is NULL");
     HIP_TRY(hipSetDevice(pl->device));
     HIP_TRY(hipDeviceSynchronize());           // no launch of this plan may still be running on the old choice
-    const bool direct = pl->force_direct_mask, valu = pl->fir_valu;
+    const bool direct = pl->force_direct_mask, valu = pl->fir_valu, dvalu = pl->dft_valu;
     const int cap = pl->max_spw;
     switch (option) {
     case WOFDM_OPT_FIR_VALU: pl->fir_valu = value != 0; break;
@@ -494,10 +563,11 @@ int wofdm_plan_set_option(wofdm_plan *pl, int32_t option, int32_t value)
         pl->max_spw = value;
         break;
     case WOFDM_OPT_TXMASK_DIRECT: pl->force_direct_mask = value != 0; break;
+    case WOFDM_OPT_DFT_VALU: pl->dft_valu = value != 0; break;
     default: return fail(WOFDM_E_INVALID, "unknown option %d", (int)option);
     }
     const int rc = configure(pl);
-    if (rc != WOFDM_OK) { pl->force_direct_mask = direct; pl->fir_valu = valu; pl->max_spw = cap; }
+    if (rc != WOFDM_OK) { pl->force_direct_mask = direct; pl->fir_valu = valu; pl->max_spw = cap; pl->dft_valu = dvalu; }
     // (the noise scratch rows are sized per layout: a forced grid in launch() regrows them, a new layout here)
     if (rc == WOFDM_OK) {
         const size_t row = wofdm_noise_scratch_len(pl->g.N, pl->spw);

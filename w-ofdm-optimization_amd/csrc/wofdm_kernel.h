@@ -16,7 +16,8 @@ struct wofdm_kdump {          // device pointers, all may be null
 };
 
 // LDS carve: fixed-size regions first (compile-time offsets), the frame buffer last.
-//   tw    float2[N]          twiddles exp(-2 pi i m / N)
+//   tw    float2[N]          twiddles exp(-2 pi i m / N)    (N = 256: 6 KB -- the matrix-pipe DFT layouts 10 / 11 keep the
+//                            stage-1 operands and the inter-stage twiddles of wofdm_dftc there, [6][64] 16-byte rows)
 //   g     float2[N]          pilot equaliser X0/Y0
 //   sums  float [2][32]      per-wave signal / noise power partials, double-buffered by frame parity
 //   flags int   [64]         [w] = last loop iteration whose phase A wave w has finished,
@@ -31,7 +32,8 @@ struct wofdm_kdump {          // device pointers, all may be null
 template <int N> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
-    static constexpr int off_g = off_tw + 8 * N;
+    static constexpr int TW_BYTES = N == 256 ? 6 * 64 * 16 : 8 * N;
+    static constexpr int off_g = off_tw + TW_BYTES;
     static constexpr int off_sums = off_g + 8 * N;
     static constexpr int off_flags = off_sums + 4 * 64;
     static constexpr int off_wtx = off_flags + 4 * 64;
@@ -55,6 +57,10 @@ struct wofdm_kparams {
     uint64_t items_q, items_r;     // (cell, frame) items per workgroup: q, and one more for the first r
     uint32_t seed_lo, seed_hi;
     unsigned long long *counts;   // [cells][4], entry 0 = cell inject_base_cell
+    // layouts 10 / 11 (both 256-point transforms on the matrix pipe): operand table [10][64] x 16 bytes (wofdm_abi.hip,
+    // build_dftc) and the power of two per (snr, channel) that centres the received samples in the f16 range
+    const uint4 *dftc;
+    const float *rx_scale;
     const uint8_t *labels;  // inject: [cells][frames][S][N]
     const float2  *unit_noise;    // inject: [cells][frames][NL]
     float2 *noise_scratch;        // generate, N >= WOFDM_NOISE_SCRATCH_MIN_N: [grid][16][RB][64]
@@ -91,8 +97,11 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // 6 / 7 = four symbols per wave with the FIR on the matrix pipe (wofdm_firm_tiles tiles of 128
 // samples per wave, two samples per lane and tile)
 // 8 = one symbol per wave with the FIR on the matrix pipe (N >= 512; wofdm_fir8_tiles tiles per wave)
-static inline bool wofdm_is_firm(int spw) { return spw >= 6 && spw <= 8; }
-static inline int wofdm_firm_tiles(int spw) { return spw == 7 ? 10 : 9; }
+// 10 / 11 = 6 / 7 with both 256-point transforms on the matrix pipe as well (lane l holds elements l + 64 j of each of the
+// wave's four symbols)
+static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11; }
+static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 8) || wofdm_is_mdft(spw); }
+static inline int wofdm_firm_tiles(int spw) { return (spw == 7 || spw == 11) ? 10 : 9; }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
 #define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
@@ -109,14 +118,14 @@ static inline int wofdm_nsym(int spw) { return spw == 8 ? 1 : ((spw == 5 || wofd
 #ifndef WOFDM_MAX_SPW
 #define WOFDM_MAX_SPW 4
 #endif
-static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool firm = true)
+static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool firm = true, bool mdft = true)
 {
     // (the matrix-pipe kernels take a stride of at least n_fft for granted: their tiles below SPW n_fft
     // samples carry no validity tests)
     firm = firm && B >= n_fft;
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
-        if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return 6;
-        if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return 7;
+        if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return mdft ? 10 : 6;
+        if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return mdft ? 11 : 7;
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
@@ -143,7 +152,7 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 }
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = 8 * N + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int fixed = (N == 256 ? 6 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
     return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
 }

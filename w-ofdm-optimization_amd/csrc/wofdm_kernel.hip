@@ -123,6 +123,7 @@ __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 // (rms) of the frame's rms, the fp32 VALU form by 1.1e-7: both at the rounding floor of the fp32 stages around them
 // (tests/test_gpu_parity.py::test_fir_precision_matrix_pipe_vs_valu).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef h2 hpair;                  // (phase C has a local named h2)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -576,6 +577,91 @@ __device__ __forceinline__ void fill_twiddles_qw(v2f *tw, int tid, int nthreads)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// N = 256 on the matrix pipe (layouts 10, 11): 256 = 16 . 16, both stages as 16-point DFT matrix products in split f16
+// with fp32 accumulation, NO LDS exchange and no cross-lane traffic.  Lane (a = lane % 16, g = lane / 16) holds elements
+// lane + 64 j, j < 4, of each of the wave's four symbols, as input and as output.  With n = 16 n1 + n2, k = k1 + 16 k2,
+// th = exp(-2 pi i / 16), om = exp(-2 pi i / 256):
+//   stage 1   T[n2][k1] = sum_n1 x[16 n1 + n2] th^(n1 k1):  the DATA is the A operand (row m = n2 = a; K slot (g, j) <-> n1 =
+//             g + 4 j, i.e. the lane's own four words), the DFT matrix the B operand (column k1); the result comes back as
+//             lane (k1 = a, g), element j' = row n2 = 4 g + j' -- which is where the B operand of stage 2 wants it;
+//   twiddle   T' = T om^(n2 k1) = T om^((4 g + j') a): four constants per lane;
+//   stage 2   X[k1 + 16 k2] = sum_n2 th^(n2 k2) T'[n2][k1]:  the DFT matrix is the A operand with its rows permuted (row m <->
+//             k2 = m / 4 + 4 (m % 4)), so that element j'' of lane (a, g) is row 4 g + j'' <-> k2 = g + 4 j'': X[lane + 64 j''].
+// Complex products ride in the real matrices {Fr, -Fi; Fi, Fr}: K = (index, re | im) = the packed (re | im << 16) words the
+// frame's f16 planes are made of; real and imaginary outputs are two accumulators.  Every operand is an f16 pair hi + lo
+// (split_h), three terms per product (hi hi, hi lo, lo hi) as in the FIR -- the QAM symbols in front of the inverse
+// transform are small integers, exact in f16: two terms.  The inverse transform is conj(DFT(conj X)): the constellation
+// table holds the conjugates and the Tx window multiply takes the second conjugate along in a sign modifier.
+// The six (four) MFMAs of a stage are ONE asm block on its own 64-byte line, as the FIR's (WOFDM_MMA_ALIGN): two interleaved
+// in-place chains, the wait states a VALU write in front and a VALU read behind need.
+__device__ __forceinline__ void mma33(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1, h8 a2, h8 b2,
+                                      h8 a3, h8 b3, h8 a4, h8 b4, h8 a5, h8 b5)
+{
+    asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
+                 "s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %8, %9, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %10, %11, %1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %6, %7, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %12, %13, %1\n\t"
+                 "s_nop 7\n\ts_nop 3"
+                 : "=&v"(re), "=&v"(im)
+                 : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+}
+__device__ __forceinline__ void mma22(f4 &re, f4 &im, h8 a, h8 b0, h8 b1, h8 b2, h8 b3)
+{
+    asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
+                 "s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %6, %1\n\t"
+                 "s_nop 7\n\ts_nop 3"
+                 : "=&v"(re), "=&v"(im)
+                 : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+// the wave's constants of the two stages: operand rows of th^(..) for real / imaginary outputs, hi / lo halves, and the
+// inter-stage twiddles (table: wofdm_abi.hip, build_dftc; rows 0..3 and 8, 9 sit in LDS, 4..7 come from L2)
+struct mdft_consts { h8 brh, brl, bih, bil, arh, arl, aih, ail; f4 twr, twi; };
+// (t_re + i t_im) *= (twr + i twi), element-wise on the lane's four values
+__device__ __forceinline__ void mdft_twiddle(f4 &tr, f4 &ti, f4 wr, f4 wi)
+{
+    const f4 r = tr * wr - ti * wi, i = tr * wi + ti * wr;
+    tr = r; ti = i;
+}
+__device__ __forceinline__ void mdft_split4(f4 re, f4 im, h8 &hi, h8 &lo)
+{
+    uint32_t h[4], l[4];
+    split_h(mk(re.x, im.x), h[0], l[0]);
+    split_h(mk(re.y, im.y), h[1], l[1]);
+    split_h(mk(re.z, im.z), h[2], l[2]);
+    split_h(mk(re.w, im.w), h[3], l[3]);
+    hi = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+}
+// forward 256-point DFT of four split words per lane (elements lane + 64 j) -> (yr, yi), same element order
+__device__ __forceinline__ void mdft_fwd(h8 xh, h8 xl, const mdft_consts &c, f4 &yr, f4 &yi)
+{
+    f4 tr, ti;
+    mma33(tr, ti, xl, c.brh, xh, c.brl, xh, c.brh, xl, c.bih, xh, c.bil, xh, c.bih);
+    mdft_twiddle(tr, ti, c.twr, c.twi);
+    h8 th, tl;
+    mdft_split4(tr, ti, th, tl);
+    mma33(yr, yi, c.arh, tl, c.arl, th, c.arh, th, c.aih, tl, c.ail, th, c.aih, th);
+}
+// the same for exact f16 input words (no lo half)
+__device__ __forceinline__ void mdft_fwd_exact(h8 x, const mdft_consts &c, f4 &yr, f4 &yi)
+{
+    f4 tr, ti;
+    mma22(tr, ti, x, c.brl, c.brh, c.bil, c.bih);
+    mdft_twiddle(tr, ti, c.twr, c.twi);
+    h8 th, tl;
+    mdft_split4(tr, ti, th, tl);
+    mma33(yr, yi, c.arh, tl, c.arl, th, c.arh, th, c.aih, tl, c.ail, th, c.aih, th);
+}
+
 // registers -> (LDS stages) -> registers, natural order in and out, SPW symbols at once
 template <int N, int DIR, int SPW>
 __device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, const v2f *tw,
@@ -809,7 +895,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = LAY == 8 ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 7 ? 20 : 18)
+    static constexpr int RB = LAY == 8 ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? ((LAY == 7 || LAY == 11) ? 20 : 18)
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -839,9 +925,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 {
     // layouts 6, 7 (quarter-wave, four symbols per wave) and 8 (one symbol per wave, N >= 512): the
     // 21-tap FIR on the matrix pipe as a block-Toeplitz product, NT tiles of 128 samples per wave (phase B)
-    constexpr bool FIRQ = LAY == 6 || LAY == 7, FIR8 = LAY == 8, FIRM = FIRQ || FIR8;
+    // layouts 10, 11: 6, 7 with both 256-point transforms on the matrix pipe too (mdft_fwd): four symbols per wave, lane l
+    // holds elements l + 64 j of each
+    constexpr bool MDFT = LAY == 10 || LAY == 11;
+    constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT, FIR8 = LAY == 8, FIRM = FIRQ || FIR8;
     constexpr int SPW = FIR8 ? 1 : (LAY >= 5 ? 4 : LAY);     // symbols per wave
-    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 7 ? 10 : 9), PRE = WOFDM_FIRM_PRE;
+    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : ((LAY == 7 || LAY == 11) ? 10 : 9), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
     static_assert(!FIR8 || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
@@ -861,8 +950,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool FULL = geo<N>::FULL;
     // SPW = 4: quarter-wave layout (fft_qw): 16 lanes per symbol, 16 subcarriers per lane, 4-wave
     // workgroups, three of them per CU at up to 168 VGPRs
-    constexpr bool QW = SPW == 4;
-    static_assert(!QW || (N == 256 && VAR <= 1), "the quarter-wave layout is built for N = 256 without Tx mask");
+    constexpr bool QW = SPW == 4 && !MDFT;
+    static_assert(!(QW || MDFT) || (N == 256 && VAR <= 1), "the four-symbol layouts are built for N = 256 without Tx mask");
     constexpr int VS = QW ? 1 : SPW, VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, LAY>::RB, NBK = fir_geo<N, LAY>::NBK;
     constexpr bool EVEN = fir_geo<N, LAY>::EVEN;
@@ -927,7 +1016,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     if (tid < 64) flags[tid] = 0;
     if (tid < 64) sums[tid] = 0.f;                 // (waves a short frame does not have leave their partial sums at zero)
     int iter = 0;                                  // frames this workgroup has started
-    if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
+    if constexpr (MDFT) {
+        // rows 0..3 (stage-1 operands) and 8, 9 (twiddles) of the operand table, [6][64] 16-byte rows
+        u4 *dl = reinterpret_cast<u4 *>(smem + L::off_tw);
+        const u4 *dg = reinterpret_cast<const u4 *>(p.dftc);
+        for (int i = tid; i < 6 * 64; i += blockDim.x) dl[i] = dg[i < 256 ? i : i + 256];
+    } else if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
     else fill_twiddles<N>(tw, tid, (int)blockDim.x);
     // constellation table: qammod(label) (Gray, unit average power; m:248-249)
     if (tid < (1 << K)) {
@@ -936,8 +1030,19 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                                                                      : 0.15430334996209191f);
         const uint32_t gi = (uint32_t)tid >> hb, gq = (uint32_t)tid & (uint32_t)mm;
         const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2)), lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
-        qlut[tid] = mk((float)(2 * li - mm), (float)(mm - 2 * lq)) * qs;
+        if constexpr (MDFT) {
+            // matrix-pipe transforms: the CONJUGATE point as a packed f16 word of small integers (exact); the scale qs
+            // rides in the Tx window table
+            const h2 w = {(_Float16)(float)(2 * li - mm), (_Float16)(float)(2 * lq - mm)};
+            reinterpret_cast<uint32_t *>(qlut)[tid] = __builtin_bit_cast(uint32_t, w);
+        } else {
+            qlut[tid] = mk((float)(2 * li - mm), (float)(mm - 2 * lq)) * qs;
+        }
     }
+    // (constellation scale: unit average power)
+    constexpr float qscale = K == 2 ? 0.70710678118654752f : (K == 4 ? 0.31622776601683794f : 0.15430334996209191f);
+    const uint32_t *qlw = reinterpret_cast<const uint32_t *>(qlut);
+    (void)qlw;
     // Tx mask: periodic extension of the mask's impulse response behind the frame buffer,
     // rg[t] = g[(t - RG_OFF) mod (2P-1)], so that the stage below indexes it without a modulo
     v2f *rg = fbuf + gm[WOFDM_G_FBUF] + gm[WOFDM_G_S] * gm[WOFDM_G_BETA];
@@ -1030,17 +1135,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // counts at most 6144 bit errors per frame)
         if (cell != cur_cell || nfr == (1u << 14)) {
             if (cur_cell != 0xFFFFFFFFu) flush(cur_cell);
+            // (matrix-pipe transforms: the Rx window table carries the cell's power of two that centres the received
+            // samples in the f16 range -- everything behind it is homogeneous in that scale -- so it is refilled per cell)
+            const bool refill = pair != cur_pair || (MDFT && cell != cur_cell);
             cur_cell = cell;
-            if (pair != cur_pair) {
+            if (refill) {
                 __syncthreads();
                 // 1/N of the IDFT (dftmtx(N)'/N, m:370) is folded into the Tx window copy
                 const int P = gm[WOFDM_G_P], delta = gm[WOFDM_G_DELTA];
                 int t0 = tid;                      // (opaque: keeps the fill loops' addresses out of
                 asm volatile("" : "+v"(t0));       // the frame loop's live set)
+                const float txs = MDFT ? p.tx_scale * qscale : p.tx_scale;
+                float rxs = 1.0f;
+                if constexpr (MDFT) rxs = p.rx_scale[sn * n_ch + ch];
                 for (int i = t0; i < P; i += blockDim.x)
-                    wtx[i] = g_wtx[(size_t)pair * P + i] * p.tx_scale;
+                    wtx[i] = g_wtx[(size_t)pair * P + i] * txs;
                 for (int i = t0; i < N + delta; i += blockDim.x)
-                    wrx[i] = g_wrx[(size_t)pair * (N + delta) + i];
+                    wrx[i] = g_wrx[(size_t)pair * (N + delta) + i] * rxs;
                 __syncthreads();
                 cur_pair = pair;
             }
@@ -1063,6 +1174,22 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
         v2f v[VS][VB][4];
         uint32_t lab[VS][VB];
+        // matrix-pipe transforms: the spectra of the wave's four symbols, real and imaginary parts apart (element j of
+        // symbol u = subcarrier lane + 64 j)
+        f4 yr[4], yi[4];
+        (void)yr; (void)yi;
+        auto mdft_load = [&]() {
+            mdft_consts c;
+            const u4 *dl = reinterpret_cast<const u4 *>(smem + L::off_tw) + lane;
+            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + 256 + lane;
+            c.arh = __builtin_bit_cast(h8, dg[0]); c.arl = __builtin_bit_cast(h8, dg[64]);
+            c.aih = __builtin_bit_cast(h8, dg[128]); c.ail = __builtin_bit_cast(h8, dg[192]);
+            c.brh = __builtin_bit_cast(h8, dl[0]); c.brl = __builtin_bit_cast(h8, dl[64]);
+            c.bih = __builtin_bit_cast(h8, dl[128]); c.bil = __builtin_bit_cast(h8, dl[192]);
+            c.twr = __builtin_bit_cast(f4, dl[256]); c.twi = __builtin_bit_cast(f4, dl[320]);
+            return c;
+        };
+        (void)mdft_load;
         // element ownership: symbol of register slot u, subcarrier of (q, r)
         const int usq = QW ? (lane >> 4) : 0, llq = lane & 15;
         auto sym_of = [&](int u) { return QW ? s0 + usq : s0 + u; };
@@ -1145,6 +1272,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             wave_sync();
         }
         STAMPF(8);
+        uint32_t xw[4][4];                 // matrix-pipe transforms: the conjugate QAM points as packed f16 words
+        (void)xw;
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const int s = sym_of(u);
@@ -1174,6 +1303,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             Lb = (bw[(bit >> 5) + r * (NQ * ks / 32)] >> (bit & 31u)) & lmask;
                         }
                         lab[u][q] |= Lb << (8 * r);
+                        if constexpr (MDFT) {
+                            xw[u][r] = qlw[Lb];
+                            if constexpr (ALLOC) {
+                                if ((am >> (8 * r)) & 0x80u) xw[u][r] = 0u;
+                            }
+                            if (DUMP) {
+                                const hpair hw = __builtin_bit_cast(hpair, xw[u][r]);
+                                if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
+                                if (p.dump.X) p.dump.X[s * N + n] = make_float2((float)hw.x * qscale, -(float)hw.y * qscale);
+                            }
+                        } else {
                         v[u][q][r] = qlut[Lb];
                         if constexpr (ALLOC) {
                             if ((am >> (8 * r)) & 0x80u) v[u][q][r] = mk(0.f, 0.f);
@@ -1181,6 +1321,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         if (DUMP) {
                             if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
                             if (p.dump.X) p.dump.X[s * N + n] = make_float2(v[u][q][r].x, v[u][q][r].y);
+                        }
                         }
                     }
                     if constexpr (ALLOC) lab[u][q] |= am;
@@ -1193,7 +1334,24 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPF(9);
-        if constexpr (QW) fft_qw<+1>(v, row(usq), tw, llq);
+        f4 xr[4], xi[4];                   // matrix-pipe transforms: DFT(conj X) = conj(N x[t])
+        (void)xr; (void)xi;
+        if constexpr (MDFT) {
+            const mdft_consts dc = mdft_load();
+            f4 tr[4], ti[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const h8 xa = __builtin_bit_cast(h8, (u4){xw[u][0], xw[u][1], xw[u][2], xw[u][3]});
+                mma22(tr[u], ti[u], xa, dc.brl, dc.brh, dc.bil, dc.bih);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mdft_twiddle(tr[u], ti[u], dc.twr, dc.twi);
+                h8 th, tl;
+                mdft_split4(tr[u], ti[u], th, tl);
+                mma33(xr[u], xi[u], dc.arh, tl, dc.arl, th, dc.arh, th, dc.aih, tl, dc.ail, th, dc.aih, th);
+            }
+        } else if constexpr (QW) fft_qw<+1>(v, row(usq), tw, llq);
         else fft_wave<N, +1, SPW>(v, fbw, B, tw, lane);     // v = N x[t]
         STAMPF(10);
 
@@ -1288,6 +1446,62 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             };
             if (body_tail) tx8(std::true_type{});
             else tx8(std::false_type{});
+        } else if constexpr (MDFT) {
+            // four symbols, element j of symbol u = sample t = lane + 64 j: 64 consecutive words per store.  The sample is
+            // the conjugate of (xr, xi): the sign rides in the window multiply.
+            const bool body_tail = rho < gq[WOFDM_G_BETA];
+            const float *pW = wtx + (lane + mu), *pWp = pW - N;
+            auto txm = [&](auto body_tail_c, auto small_c) {
+            constexpr int CPB = decltype(small_c)::value ? 48 : L::CPCS_MAX;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u;
+                uint32_t *hrow = Hp + PRE + s * B;
+                const int Bs = (s == S - 1) ? 0x3fffffff : B;
+                const int DtH = 2 * tail_off + s * TS - (PRE + (s + 1) * B);
+                const int DtL = DtH + S * TS - plen;
+                uint32_t *pH = hrow + (lane + mu), *pL = pH + plen;
+                uint32_t *pHp = pH - N, *pLp = pL - N;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 64 * j, t = lane + e;
+                    const v2f x = mk(xr[u][j], -xi[u][j]);
+                    uint32_t hi, lo;
+                    if constexpr (decltype(body_tail_c)::value) {
+                        const int i = t + mu;
+                        split_h(x * wtx[i], hi, lo);
+                        const bool tl = i >= Bs;
+                        hrow[i + (tl ? DtH : 0)] = hi;
+                        hrow[i + plen + (tl ? DtL : 0)] = lo;
+                    } else {
+                        split_h(x * pW[e], hi, lo);
+                        pH[e] = hi;
+                        pL[e] = lo;
+                    }
+                    if (e + 63 >= N - CPB)
+                        if (e + 63 >= N - mu) {
+                            if (t >= N - mu) {
+                                split_h(x * pWp[e], hi, lo);
+                                pHp[e] = hi;
+                                pLp[e] = lo;
+                            }
+                        }
+                    if (e < CPB)
+                        if (e < rho) {
+                            if (t < rho) {
+                                const int i = t + mu + N;
+                                split_h(x * wtx[i], hi, lo);
+                                const bool tl = i >= Bs;
+                                hrow[i + (tl ? DtH : 0)] = hi;
+                                hrow[i + plen + (tl ? DtL : 0)] = lo;
+                            }
+                        }
+                }
+            }
+            };
+            const bool small = mu <= 48 && rho <= 48;
+            if (body_tail) { if (small) txm(std::true_type{}, std::true_type{}); else txm(std::true_type{}, std::false_type{}); }
+            else { if (small) txm(std::false_type{}, std::true_type{}); else txm(std::false_type{}, std::false_type{}); }
         } else if constexpr (FIRQ) {
             // the same copies, every sample split into its two packed-f16 words; the fall tail goes to
             // the tail planes, DtH / DtL words away from the row's word in plane H / L
@@ -2099,10 +2313,39 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPF(14);
-        if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
+        if constexpr (MDFT) {
+            const mdft_consts dc = mdft_load();
+            f4 tr[4], ti[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split_h(v[u][0][r], h[r], l[r]);
+                const h8 xh = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
+                const h8 xl = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                mma33(tr[u], ti[u], xl, dc.brh, xh, dc.brl, xh, dc.brh, xl, dc.bih, xh, dc.bil, xh, dc.bih);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mdft_twiddle(tr[u], ti[u], dc.twr, dc.twi);
+                h8 th, tl;
+                mdft_split4(tr[u], ti[u], th, tl);
+                mma33(yr[u], yi[u], dc.arh, tl, dc.arl, th, dc.arh, th, dc.aih, tl, dc.ail, th, dc.aih, th);
+            }
+        } else if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
         else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
         STAMPF(15);
 
+        if constexpr (MDFT) {
+            if (DUMP && p.dump.Y) {
+                const float us = p.dump_unscale_rx / p.rx_scale[sn * n_ch + ch];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        p.dump.Y[(s0 + u) * N + lane + 64 * j] = make_float2(yr[u][j] * us, yi[u][j] * us);
+            }
+        } else
         if (DUMP && p.dump.Y) {
 #pragma unroll
             for (int u = 0; u < VS; ++u)
@@ -2115,7 +2358,33 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                                                                                   v[u][q][r].y * (FIRM ? p.dump_unscale_rx : 1.f));
                 }
         }
-        if (QW && wv == 0) {
+        if constexpr (MDFT) {
+            // the pilot is symbol slot 0 of wave 0, four subcarriers per lane; G = X0 / Y0 (X0 as the table's small integers:
+            // the demapper's levels are scaled to match) goes out as one 16-byte row of real and one of imaginary parts
+            if (wv == 0) {
+                f4 gr, gi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t Lb = (lab[0][0] >> (8 * j)) & 0xFFu;
+                    const hpair hw = __builtin_bit_cast(hpair, qlw[Lb & lmask]);
+                    float x0r = (float)hw.x, x0i = -(float)hw.y;
+                    if constexpr (ALLOC) {
+                        if (Lb & 0x80u) { x0r = 0.f; x0i = 0.f; }
+                    }
+                    const float y0r = yr[0][j], y0i = yi[0][j];
+                    const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
+                    gr[j] = (x0r * y0r + x0i * y0i) * inv;                 // X0 conj(Y0) / |Y0|^2
+                    gi[j] = (x0i * y0r - x0r * y0i) * inv;
+                }
+                f4 *G4 = reinterpret_cast<f4 *>(G);
+                G4[lane] = gr;
+                G4[64 + lane] = gi;
+                if constexpr (RELAXF) {
+                    wave_sync();
+                    post_flag(&flags[16], iter, lane);
+                }
+            }
+        } else if (QW && wv == 0) {
             // quarter-wave layout: the pilot symbol sits in lanes 0..15 of wave 0, and every other
             // wave waits for its equaliser.  Those 16 lanes only hand their Y0 and packed labels
             // over (through G itself and the pilot's now idle frame slice); all 64 lanes then
@@ -2182,6 +2451,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ D: equalise, demap, count
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         uint32_t be_f = 0, se_f = 0;                   // this frame's errors of the lane (SCALAR_ACC)
+        f4 g4r = {0.f, 0.f, 0.f, 0.f}, g4i = g4r;
+        if constexpr (MDFT) {
+            g4r = reinterpret_cast<const f4 *>(G)[lane];
+            g4i = reinterpret_cast<const f4 *>(G)[64 + lane];
+        }
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
             const int s = sym_of(u);
@@ -2189,6 +2463,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                 for (int q = 0; q < VB; ++q) {
                     if (owns(q)) {
+                        // (matrix-pipe transforms: the equalised symbols in the table's integer scale, four at once)
+                        f4 ehr = g4r, ehi = g4r, lvi = g4r, lvq = g4r;
+                        if constexpr (MDFT) {
+                            ehr = yr[u] * g4r - yi[u] * g4i;
+                            ehi = yr[u] * g4i + yi[u] * g4r;
+                            lvi = ehr * 0.5f + 0.5f * (float)m1;
+                            lvq = ehi * -0.5f + 0.5f * (float)m1;
+                        }
                         // The four subcarriers of a butterfly are demapped together, one byte each of the
                         // packed words: per-axis level index = rne(clamp(+-x qinv/2 + m1/2)) converted,
                         // clamped below and packed by v_cvt_pk_u8_f32; binary reflected Gray code on all
@@ -2198,9 +2480,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = sub_of(q, r);
-                            const v2f xh = cmul(v[u][q][r], G[n]);
-                            const v2f lev = __builtin_elementwise_fma(
-                                xh, mk(0.5f * qinv, -0.5f * qinv), mk(0.5f * (float)m1, 0.5f * (float)m1));
+                            v2f xh, lev;
+                            if constexpr (MDFT) {
+                                xh = mk(ehr[r], ehi[r]) * qscale;
+                                lev = mk(lvi[r], lvq[r]);
+                            } else {
+                                xh = cmul(v[u][q][r], G[n]);
+                                lev = __builtin_elementwise_fma(
+                                    xh, mk(0.5f * qinv, -0.5f * qinv), mk(0.5f * (float)m1, 0.5f * (float)m1));
+                            }
                             iw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lev.x, (float)m1), r, iw);
                             qw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lev.y, (float)m1), r, qw);
                             if (DUMP && p.dump.Xhat) p.dump.Xhat[(s - 1) * N + n] = make_float2(xh.x, xh.y);
@@ -2564,6 +2852,10 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
             return var ? pick_mode<N, K, 8, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 8, WOFDM_VAR_PLAIN>(mode);
     }
     if constexpr (N == 256) {
+        if ((spw == 10 || spw == 11) && var <= WOFDM_VAR_ALLOC) {
+            if (spw == 10) return var ? pick_mode<N, K, 10, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 10, WOFDM_VAR_PLAIN>(mode);
+            return var ? pick_mode<N, K, 11, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 11, WOFDM_VAR_PLAIN>(mode);
+        }
         if (spw >= 4 && spw <= 7 && var <= WOFDM_VAR_ALLOC) {
             if (spw == 4) return var ? pick_mode<N, K, 4, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 4, WOFDM_VAR_PLAIN>(mode);
             if (spw == 5) return var ? pick_mode<N, K, 5, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 5, WOFDM_VAR_PLAIN>(mode);
