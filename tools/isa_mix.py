@@ -71,7 +71,7 @@ def kernels(lines):
             meta[cur][m.group(1)] = int(m.group(2))
     for st, name in starts:
         end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
-        tag = re.search(r"ILi(\d+)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)", name).groups()
+        tag = re.search(r"ILi(\d+)ELi(\d)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)", name).groups()
         yield tag, name, lines[st:end + 1], meta.get(name, {})
 
 

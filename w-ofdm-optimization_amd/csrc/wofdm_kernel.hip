@@ -1017,10 +1017,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     if (tid < 64) sums[tid] = 0.f;                 // (waves a short frame does not have leave their partial sums at zero)
     int iter = 0;                                  // frames this workgroup has started
     if constexpr (MDFT) {
-        // rows 0..3 (stage-1 operands) and 8, 9 (twiddles) of the operand table, [6][64] 16-byte rows
+        // rows 0..3 (stage-1 operands), 4, 6 (hi halves of the stage-2 operands) and 8, 9 (twiddles) of the operand
+        // table, [8][64] 16-byte rows; rows 5, 7 (the lo halves of stage 2, the last ones a transform needs) come from L2,
+        // requested at the start of the phase
         u4 *dl = reinterpret_cast<u4 *>(smem + L::off_tw);
         const u4 *dg = reinterpret_cast<const u4 *>(p.dftc);
-        for (int i = tid; i < 6 * 64; i += blockDim.x) dl[i] = dg[i < 256 ? i : i + 256];
+        for (int i = tid; i < 8 * 64; i += blockDim.x) {
+            const int r = i >> 6, src = r < 4 ? r : (r == 4 ? 4 : (r == 5 ? 6 : r + 2));
+            dl[i] = dg[64 * src + (i & 63)];
+        }
     } else if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
     else fill_twiddles<N>(tw, tid, (int)blockDim.x);
     // constellation table: qammod(label) (Gray, unit average power; m:248-249)
@@ -1031,9 +1036,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const uint32_t gi = (uint32_t)tid >> hb, gq = (uint32_t)tid & (uint32_t)mm;
         const int li = (int)(gi ^ (gi >> 1) ^ (gi >> 2)), lq = (int)(gq ^ (gq >> 1) ^ (gq >> 2));
         if constexpr (MDFT) {
-            // matrix-pipe transforms: the CONJUGATE point as a packed f16 word of small integers (exact); the scale qs
-            // rides in the Tx window table
-            const h2 w = {(_Float16)(float)(2 * li - mm), (_Float16)(float)(2 * lq - mm)};
+            // matrix-pipe transforms: the point with real and imaginary part SWAPPED (IDFT(X) = swap(DFT(swap X)): no sign
+            // anywhere) as a packed f16 word of small integers (exact); the scale qs rides in the Tx window table
+            const h2 w = {(_Float16)(float)(mm - 2 * lq), (_Float16)(float)(2 * li - mm)};
             reinterpret_cast<uint32_t *>(qlut)[tid] = __builtin_bit_cast(uint32_t, w);
         } else {
             qlut[tid] = mk((float)(2 * li - mm), (float)(mm - 2 * lq)) * qs;
@@ -1178,18 +1183,24 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // symbol u = subcarrier lane + 64 j)
         f4 yr[4], yi[4];
         (void)yr; (void)yi;
-        auto mdft_load = [&]() {
+        struct mdft_early { u4 arl, ail; };
+        auto mdft_request = [&]() {                     // the two rows that come from L2: asked for early in the phase
+            mdft_early e;
+            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + lane;
+            e.arl = dg[5 * 64]; e.ail = dg[7 * 64];
+            return e;
+        };
+        auto mdft_load = [&](const mdft_early &e) {
             mdft_consts c;
             const u4 *dl = reinterpret_cast<const u4 *>(smem + L::off_tw) + lane;
-            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + 256 + lane;
-            c.arh = __builtin_bit_cast(h8, dg[0]); c.arl = __builtin_bit_cast(h8, dg[64]);
-            c.aih = __builtin_bit_cast(h8, dg[128]); c.ail = __builtin_bit_cast(h8, dg[192]);
             c.brh = __builtin_bit_cast(h8, dl[0]); c.brl = __builtin_bit_cast(h8, dl[64]);
             c.bih = __builtin_bit_cast(h8, dl[128]); c.bil = __builtin_bit_cast(h8, dl[192]);
-            c.twr = __builtin_bit_cast(f4, dl[256]); c.twi = __builtin_bit_cast(f4, dl[320]);
+            c.arh = __builtin_bit_cast(h8, dl[256]); c.aih = __builtin_bit_cast(h8, dl[320]);
+            c.twr = __builtin_bit_cast(f4, dl[384]); c.twi = __builtin_bit_cast(f4, dl[448]);
+            c.arl = __builtin_bit_cast(h8, e.arl); c.ail = __builtin_bit_cast(h8, e.ail);
             return c;
         };
-        (void)mdft_load;
+        (void)mdft_load; (void)mdft_request;
         // element ownership: symbol of register slot u, subcarrier of (q, r)
         const int usq = QW ? (lane >> 4) : 0, llq = lane & 15;
         auto sym_of = [&](int u) { return QW ? s0 + usq : s0 + u; };
@@ -1259,6 +1270,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             else
                 return fbw + u * B;
         };
+        mdft_early dce;
+        if constexpr (MDFT) dce = mdft_request();
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
             if (lane < SPW * bps) {
@@ -1311,7 +1324,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             if (DUMP) {
                                 const hpair hw = __builtin_bit_cast(hpair, xw[u][r]);
                                 if (p.dump.labels_tx) p.dump.labels_tx[s * N + n] = (uint8_t)Lb;
-                                if (p.dump.X) p.dump.X[s * N + n] = make_float2((float)hw.x * qscale, -(float)hw.y * qscale);
+                                if (p.dump.X) p.dump.X[s * N + n] = make_float2((float)hw.y * qscale, (float)hw.x * qscale);
                             }
                         } else {
                         v[u][q][r] = qlut[Lb];
@@ -1328,16 +1341,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     // opaque at the large sizes: otherwise the unpacked labels themselves stay alive
                     // (and spill) all the way to the pilot estimate and the demapper instead of
                     // this one word
-                    if constexpr (N >= 512 || QW) asm volatile("" : "+v"(lab[u][q]));
+                    if constexpr (N >= 512 || QW || MDFT) asm volatile("" : "+v"(lab[u][q]));
                 }
             }
         }
         wave_sync();
         STAMPF(9);
-        f4 xr[4], xi[4];                   // matrix-pipe transforms: DFT(conj X) = conj(N x[t])
+        f4 xr[4], xi[4];                   // matrix-pipe transforms: DFT(swap X) = swap(N x[t]): xr = imaginary, xi = real parts
         (void)xr; (void)xi;
         if constexpr (MDFT) {
-            const mdft_consts dc = mdft_load();
+            const mdft_consts dc = mdft_load(dce);
             f4 tr[4], ti[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1447,56 +1460,82 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             if (body_tail) tx8(std::true_type{});
             else tx8(std::false_type{});
         } else if constexpr (MDFT) {
-            // four symbols, element j of symbol u = sample t = lane + 64 j: 64 consecutive words per store.  The sample is
-            // the conjugate of (xr, xi): the sign rides in the window multiply.
+            // four symbols, element j of symbol u = sample t = lane + 64 j: 64 consecutive words per store.  The transform
+            // returned swap(N x[t]): the real parts are in xi, the imaginary parts in xr.  Whether a lane's element has a
+            // prefix / suffix copy does not depend on the symbol: ONE exec-masked region per element for all four symbols.
             const bool body_tail = rho < gq[WOFDM_G_BETA];
-            const float *pW = wtx + (lane + mu), *pWp = pW - N;
-            auto txm = [&](auto body_tail_c, auto small_c) {
-            constexpr int CPB = decltype(small_c)::value ? 48 : L::CPCS_MAX;
+            const int i0 = lane + mu;                               // position of element 0 in its symbol's row
+            uint32_t *pH0 = Hp + PRE + s0 * B + i0;
+            const float *pW = wtx + i0;
+            // word offsets from a row's position to the same position of its fall tail (the last symbol of the frame has
+            // no successor: its tail stays in the frame buffer)
+            int dtH[4], dtL[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int s = s0 + u;
-                uint32_t *hrow = Hp + PRE + s * B;
-                const int Bs = (s == S - 1) ? 0x3fffffff : B;
-                const int DtH = 2 * tail_off + s * TS - (PRE + (s + 1) * B);
-                const int DtL = DtH + S * TS - plen;
-                uint32_t *pH = hrow + (lane + mu), *pL = pH + plen;
-                uint32_t *pHp = pH - N, *pLp = pL - N;
+                const bool last = s == S - 1;
+                dtH[u] = last ? 0 : 2 * tail_off + s * TS - (PRE + (s + 1) * B);
+                dtL[u] = last ? 0 : dtH[u] + S * TS - plen;
+            }
+            auto txm = [&](auto body_tail_c, auto small_c) {
+            constexpr int CPB = decltype(small_c)::value ? 48 : L::CPCS_MAX;
+            const v2f w01 = mk(pW[0], pW[64]), w23 = mk(pW[128], pW[192]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t *pH = pH0 + u * B, *pL = pH + plen;
+                const v2f re01 = mk(xi[u].x, xi[u].y) * w01, re23 = mk(xi[u].z, xi[u].w) * w23;
+                const v2f im01 = mk(xr[u].x, xr[u].y) * w01, im23 = mk(xr[u].z, xr[u].w) * w23;
+                const float re[4] = {re01.x, re01.y, re23.x, re23.y}, im[4] = {im01.x, im01.y, im23.x, im23.y};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int e = 64 * j, t = lane + e;
-                    const v2f x = mk(xr[u][j], -xi[u][j]);
                     uint32_t hi, lo;
+                    split_h(mk(re[j], im[j]), hi, lo);
                     if constexpr (decltype(body_tail_c)::value) {
-                        const int i = t + mu;
-                        split_h(x * wtx[i], hi, lo);
-                        const bool tl = i >= Bs;
-                        hrow[i + (tl ? DtH : 0)] = hi;
-                        hrow[i + plen + (tl ? DtL : 0)] = lo;
+                        const bool tl = i0 + 64 * j >= B;               // (dtH, dtL are zero for the last symbol)
+                        pH[64 * j + (tl ? dtH[u] : 0)] = hi;
+                        pL[64 * j + (tl ? dtL[u] : 0)] = lo;
                     } else {
-                        split_h(x * pW[e], hi, lo);
-                        pH[e] = hi;
-                        pL[e] = lo;
+                        pH[64 * j] = hi;
+                        pL[64 * j] = lo;
                     }
-                    if (e + 63 >= N - CPB)
-                        if (e + 63 >= N - mu) {
-                            if (t >= N - mu) {
-                                split_h(x * pWp[e], hi, lo);
-                                pHp[e] = hi;
-                                pLp[e] = lo;
-                            }
-                        }
-                    if (e < CPB)
-                        if (e < rho) {
-                            if (t < rho) {
-                                const int i = t + mu + N;
-                                split_h(x * wtx[i], hi, lo);
-                                const bool tl = i >= Bs;
-                                hrow[i + (tl ? DtH : 0)] = hi;
-                                hrow[i + plen + (tl ? DtL : 0)] = lo;
-                            }
-                        }
                 }
+            }
+            // prefix: samples t >= N - mu once more, N words in front
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (64 * j + 63 >= N - CPB)
+                    if (64 * j + 63 >= N - mu) {
+                        if (lane + 64 * j >= N - mu) {
+                            const float w = pW[64 * j - N];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                uint32_t *pH = pH0 + u * B, *pL = pH + plen;
+                                uint32_t hi, lo;
+                                split_h(mk(xi[u][j] * w, xr[u][j] * w), hi, lo);
+                                pH[64 * j - N] = hi;
+                                pL[64 * j - N] = lo;
+                            }
+                        }
+                    }
+            }
+            // suffix: samples t < rho once more, N words behind -- in the fall tail from position B on
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (64 * j < CPB)
+                    if (64 * j < rho) {
+                        if (lane + 64 * j < rho) {
+                            const float w = pW[64 * j + N];
+                            const bool tl = i0 + 64 * j + N >= B;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                uint32_t *pH = pH0 + u * B, *pL = pH + plen;
+                                uint32_t hi, lo;
+                                split_h(mk(xi[u][j] * w, xr[u][j] * w), hi, lo);
+                                pH[64 * j + N + (tl ? dtH[u] : 0)] = hi;
+                                pL[64 * j + N + (tl ? dtL[u] : 0)] = lo;
+                            }
+                        }
+                    }
             }
             };
             const bool small = mu <= 48 && rho <= 48;
@@ -2208,6 +2247,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             Pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
         }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
+        mdft_early dce;
+        if constexpr (MDFT) dce = mdft_request();
 #ifdef WOFDM_AUDIT
         aud_g = g; aud_ps = Ps; aud_pn = Pn;
 #endif
@@ -2218,16 +2259,21 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const bool all_full = !DUMP && LW == 128 * NT;
             v2f *rxb = (FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B)) + jl;
             const int dlt = FIR8 ? 0 : (plen - 4 * B) / 2;
+            v2f *rxb1 = rxb + dlt;                                  // the lane's base in the plane-L chunk (samples from 2B on)
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
+            // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
+            // one select between the two per-lane bases plus an instruction immediate)
+            auto noise_scale = [&](auto full_c) {
+            constexpr bool FULLC = decltype(full_c)::value;
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
-                bool valid = all_full || jr < LW;
+                bool valid = FULLC || jr < LW;
                 if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
-                v2f *dst = rxb + 128 * G + (!FIR8 && jr >= 2 * B ? dlt : 0);
-                if (!all_full) dst = valid ? dst : sink;
+                v2f *dst = (FIR8 || jl < 2 * B - 128 * G ? rxb : rxb1) + 128 * G;
+                if (!FULLC) dst = valid ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
                 if (DUMP && p.dump.rx) {
                     float2 *dr = valid ? p.dump.rx + s0 * B + jr : p.dump.sink;
@@ -2236,6 +2282,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     dr[valid ? 1 : 0] = make_float2(e1.x, e1.y);
                 }
             }
+            };
+            if (all_full) noise_scale(std::true_type{});
+            else noise_scale(std::false_type{});
         } else if constexpr (DUMP) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -2314,7 +2363,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         wave_sync();
         STAMPF(14);
         if constexpr (MDFT) {
-            const mdft_consts dc = mdft_load();
+            const mdft_consts dc = mdft_load(dce);
             f4 tr[4], ti[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2367,7 +2416,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t Lb = (lab[0][0] >> (8 * j)) & 0xFFu;
                     const hpair hw = __builtin_bit_cast(hpair, qlw[Lb & lmask]);
-                    float x0r = (float)hw.x, x0i = -(float)hw.y;
+                    float x0r = (float)hw.y, x0i = (float)hw.x;
                     if constexpr (ALLOC) {
                         if (Lb & 0x80u) { x0r = 0.f; x0i = 0.f; }
                     }
