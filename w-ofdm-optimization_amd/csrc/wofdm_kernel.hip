@@ -593,13 +593,22 @@ __device__ __forceinline__ void fill_twiddles_qw(v2f *tw, int tid, int nthreads)
 // (split_h), three terms per product (hi hi, hi lo, lo hi) as in the FIR -- the QAM symbols in front of the inverse
 // transform are small integers, exact in f16: two terms.  The inverse transform is conj(DFT(conj X)): the constellation
 // table holds the conjugates and the Tx window multiply takes the second conjugate along in a sign modifier.
-// The six (four) MFMAs of a stage are ONE asm block on its own 64-byte line, as the FIR's (WOFDM_MMA_ALIGN): two interleaved
-// in-place chains, the wait states a VALU write in front and a VALU read behind need.
+// The six (four) MFMAs of a stage are ONE asm block: two interleaved in-place chains, the wait states a VALU write in front
+// and a VALU read behind need, destinations early-clobber (see fir_mma).  A transform is a TRAIN of such blocks a few dozen
+// cycles apart, and trains do to the SIMD's other waves what a gap inside the FIR's chain does (WOFDM_MMA_ALIGN above):
+// v_pk_*_f32 with an op_sel source swizzle returns wrong values in lanes 48..63 -- measured for every spacing from 14 to
+// 1 000 cycles and for blocks of three, four, six and eight (tools/ubench/mfma_block_train.hip, profiles/
+// r03_mfma_block_train.txt).  Every other instruction form these kernels use next to the trains stayed exact in 10^10
+// checks each under the worst train (v_pk_* with op_sel_hi broadcasts, with neg, without modifiers; v_cvt_pk_f16_f32 +
+// v_fma_mixlo/mixhi_f16).  So the guard here is the ABSENCE OF VICTIMS: the kernels of layouts 10 / 11 contain no v_pk_*
+// instruction with an op_sel swizzle (no cmul, add_mi, add_pi: the transforms were their only users), which
+// tests/test_code_layout.py checks in the built library; and since nothing in them can be hit, their blocks need no
+// cache-line alignment either.  (Kernels WITH such instructions -- every other layout -- must not share a SIMD with
+// these: one device runs one plan's launches at a time, include/wofdm.h.)
 __device__ __forceinline__ void mma33(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1, h8 a2, h8 b2,
                                       h8 a3, h8 b3, h8 a4, h8 b4, h8 a5, h8 b5)
 {
-    asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
-                 "s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t"
                  "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
                  "v_mfma_f32_16x16x32_f16 %1, %8, %9, 0\n\t"
                  "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\t"
@@ -612,8 +621,7 @@ __device__ __forceinline__ void mma33(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1
 }
 __device__ __forceinline__ void mma22(f4 &re, f4 &im, h8 a, h8 b0, h8 b1, h8 b2, h8 b3)
 {
-    asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
-                 "s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t"
                  "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
                  "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
                  "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
@@ -1491,9 +1499,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     uint32_t hi, lo;
                     split_h(mk(re[j], im[j]), hi, lo);
                     if constexpr (decltype(body_tail_c)::value) {
-                        const bool tl = i0 + 64 * j >= B;               // (dtH, dtL are zero for the last symbol)
-                        pH[64 * j + (tl ? dtH[u] : 0)] = hi;
-                        pL[64 * j + (tl ? dtL[u] : 0)] = lo;
+                        const int tlm = i0 + 64 * j >= B ? -1 : 0;      // (dtH, dtL are zero for the last symbol)
+                        pH[64 * j + (dtH[u] & tlm)] = hi;
+                        pL[64 * j + (dtL[u] & tlm)] = lo;
                     } else {
                         pH[64 * j] = hi;
                         pL[64 * j] = lo;
@@ -1525,14 +1533,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if (64 * j < rho) {
                         if (lane + 64 * j < rho) {
                             const float w = pW[64 * j + N];
-                            const bool tl = i0 + 64 * j + N >= B;
+                            const int tlm = i0 + 64 * j + N >= B ? -1 : 0;       // (a mask, not a branch per store)
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 uint32_t *pH = pH0 + u * B, *pL = pH + plen;
                                 uint32_t hi, lo;
                                 split_h(mk(xi[u][j] * w, xr[u][j] * w), hi, lo);
-                                pH[64 * j + N + (tl ? dtH[u] : 0)] = hi;
-                                pL[64 * j + N + (tl ? dtL[u] : 0)] = lo;
+                                pH[64 * j + N + (dtH[u] & tlm)] = hi;
+                                pL[64 * j + N + (dtL[u] & tlm)] = lo;
                             }
                         }
                     }
