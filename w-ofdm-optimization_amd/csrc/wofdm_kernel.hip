@@ -593,42 +593,45 @@ __device__ __forceinline__ void fill_twiddles_qw(v2f *tw, int tid, int nthreads)
 // (split_h), three terms per product (hi hi, hi lo, lo hi) as in the FIR -- the QAM symbols in front of the inverse
 // transform are small integers, exact in f16: two terms.  The inverse transform is conj(DFT(conj X)): the constellation
 // table holds the conjugates and the Tx window multiply takes the second conjugate along in a sign modifier.
-// The six (four) MFMAs of a stage are ONE asm block: two interleaved in-place chains, the wait states a VALU write in front
-// and a VALU read behind need, destinations early-clobber (see fir_mma).  A transform is a TRAIN of such blocks a few dozen
-// cycles apart, and trains do to the SIMD's other waves what a gap inside the FIR's chain does (WOFDM_MMA_ALIGN above):
-// v_pk_*_f32 with an op_sel source swizzle returns wrong values in lanes 48..63 -- measured for every spacing from 14 to
-// 1 000 cycles and for blocks of three, four, six and eight (tools/ubench/mfma_block_train.hip, profiles/
-// r03_mfma_block_train.txt).  Every other instruction form these kernels use next to the trains stayed exact in 10^10
-// checks each under the worst train (v_pk_* with op_sel_hi broadcasts, with neg, without modifiers; v_cvt_pk_f16_f32 +
-// v_fma_mixlo/mixhi_f16).  So the guard here is the ABSENCE OF VICTIMS: the kernels of layouts 10 / 11 contain no v_pk_*
-// instruction with an op_sel swizzle (no cmul, add_mi, add_pi: the transforms were their only users), which
-// tests/test_code_layout.py checks in the built library; and since nothing in them can be hit, their blocks need no
-// cache-line alignment either.  (Kernels WITH such instructions -- every other layout -- must not share a SIMD with
-// these: one device runs one plan's launches at a time, include/wofdm.h.)
+// The six (four) MFMAs of a stage are two interleaved in-place chains of compiler builtins, scheduled BY THE COMPILER among
+// the vector instructions around them (it knows the wait states an MFMA result needs; the matrix pipe works under the
+// twiddles, splits and -- in phase B -- the noise draw of the same wave instead of stalling it: C2 13.2 -> 12.65 ms).  That
+// freedom is what the other layouts must not have: an MFMA that follows a burst of MFMAs after a gap -- 7 to 1 000
+// cycles, whatever fills it -- makes v_pk_*_f32 instructions with an op_sel source swizzle return wrong values in lanes
+// 48..63 of the SIMD's OTHER waves (WOFDM_MMA_ALIGN above: a gap inside the FIR's chain; tools/ubench/mfma_block_train.hip,
+// profiles/r03_mfma_block_train.txt: trains of blocks of three, four, six, eight MFMAs at every spacing).  Every other
+// instruction form these kernels use stayed exact in 10^10 checks each beside the worst train (v_pk_* with op_sel_hi
+// broadcasts, with neg, without modifiers; v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16).  So the guard here is the ABSENCE OF
+// VICTIMS: the kernels of layouts 10 / 11 contain no v_pk_* instruction with an op_sel swizzle (no cmul, add_mi, add_pi:
+// the VALU transforms were their only users), which tests/test_code_layout.py checks in the built library.  (Kernels WITH
+// such instructions -- every other layout -- must not share a SIMD with these: one device runs one plan's launches at a
+// time, include/wofdm.h.)
+// (every operand of a chain is kept alive up to the chain's RESULT -- an empty asm that takes the result and the operands:
+// v_mfma_f32_16x16x32_f16 carries no early-clobber constraint in the compiler, which otherwise may put a destination on top
+// of the instruction's own operand; tests/test_code_layout.py looks for such an overlap in the built library)
 __device__ __forceinline__ void mma33(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1, h8 a2, h8 b2,
                                       h8 a3, h8 b3, h8 a4, h8 b4, h8 a5, h8 b5)
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %8, %9, 0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %10, %11, %1\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %6, %7, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %12, %13, %1\n\t"
-                 "s_nop 7\n\ts_nop 3"
-                 : "=&v"(re), "=&v"(im)
-                 : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, z, 0, 0, 0);
+    f4 i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, b3, z, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4, b4, i, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a5, b5, i, 0, 0, 0);
+    asm volatile("" : "+v"(r), "+v"(i) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4),
+                 "v"(a5), "v"(b5));
+    re = r; im = i;
 }
 __device__ __forceinline__ void mma22(f4 &re, f4 &im, h8 a, h8 b0, h8 b1, h8 b2, h8 b3)
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, 0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %2, %6, %1\n\t"
-                 "s_nop 7\n\ts_nop 3"
-                 : "=&v"(re), "=&v"(im)
-                 : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, z, 0, 0, 0);
+    f4 i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, z, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b3, i, 0, 0, 0);
+    asm volatile("" : "+v"(r), "+v"(i) : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    re = r; im = i;
 }
 // the wave's constants of the two stages: operand rows of th^(..) for real / imaginary outputs, hi / lo halves, and the
 // inter-stage twiddles (table: wofdm_abi.hip, build_dftc; rows 0..3 and 8, 9 sit in LDS, 4..7 come from L2)
@@ -1946,6 +1949,19 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         //    VALU read of the result needs (not interlocked: tools/ubench/mfma_gap.hip).
         auto fir_mma = [&](const bops &o) -> f4 {
             f4 d;
+            if constexpr (MDFT) {
+                // layouts 10 / 11 hold nothing a gap in this chain could corrupt (see mma33): compiler builtins, spread
+                // over the tile's noise draw (below)
+                const f4 z = {0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], o.h0, z, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], o.h1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.l0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.l1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.h0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.h1, d, 0, 0, 0);
+                asm volatile("" : "+v"(d) : "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]));
+                return d;
+            }
             asm volatile(".p2align " WOFDM_MMA_ALIGN "\n\t"
                          "s_nop 1\n\t"
                          "v_mfma_f32_16x16x32_f16 %0, %1, %5, 0\n\t"        // h_lo x_hi
@@ -1991,6 +2007,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
             }
             noise_pair(jw + jr, valid, valid, n0, n1);
+            if constexpr (MDFT && !INJECT) {
+                // the tile's six MFMAs spread over its noise draw: one MFMA, then four vector instructions (an MFMA holds
+                // the vector issue for half of its 16 cycles; interleaved A/B of 3, 4, 5, 6, 8: all within 1 %, -2.3 %
+                // against the compiler's own placement)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            }
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
             if (RENOISE && (INJECT || G >= NKEEP)) {
                 if (!INJECT) nscr[64 * G] = (f4){n0.x, n0.y, n1.x, n1.y};
