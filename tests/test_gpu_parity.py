@@ -56,7 +56,7 @@ def _expected_layout(st, n_fft, S):
         if 4 * B <= 64 * 20:
             return 5
     if n_fft >= 512 and B >= n_fft and B % 4 == 0 and B <= 128 * (9 if n_fft == 1024 else 5):
-        return 8
+        return 12
     return 2 if (n_fft <= 256 and S % 2 == 0 and 2 * B <= 64 * (2 * (n_fft // 64) + 2)) else 1
 
 
@@ -151,7 +151,7 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("fir_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (6, 7, 8, 10, 11)) == (valu == 0), layout
+            assert (layout in (6, 7, 8, 10, 11, 12)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e = np.abs(gd["conv"] - od["conv"])
         # ... and the FIR alone: against the fp64 convolution of the kernel's OWN transmitted frame (the chain's error
@@ -541,7 +541,9 @@ def _geometry_for(n_fft, layout, var):
         if layout in (6, 7):
             env["dft_valu"] = 1
         return "wtx", (32 if layout in (6, 10) else 48), 16, env        # strides 288 / 304
-    assert layout == 8
+    assert layout in (8, 12)
+    if layout == 8:
+        env["dft_valu"] = 1
     return "WOLA", 32, 16, env
 
 

@@ -127,7 +127,9 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
-    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm, !pl->dft_valu);
+    // (layout 12 -- N >= 512 with the transforms on the matrix pipe -- is built without the allocation variant)
+    const bool mdft = !pl->dft_valu && !(var == WOFDM_VAR_ALLOC && g.N >= 512);
+    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
     if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
@@ -312,7 +314,10 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     //   rows 0..3  stage 1, B operand: column k1 = a, K slot (g, j) <-> n1 = g + 4 j          (re hi, re lo, im hi, im lo)
     //   rows 4..7  stage 2, A operand: row a <-> k2 = a / 4 + 4 (a % 4), K slot (g, j) <-> n2 = 4 g + j
     //   rows 8, 9  the inter-stage twiddles exp(-2 pi i (4 g + j) a / 256), j < 4: real parts, imaginary parts (fp32)
-    std::vector<uint32_t> dftc((size_t)10 * 64 * 4);
+    //   rows 10.. (N = 512, 1024: layout 12) the twiddles in front of the last, radix-N/256 stage, exp(-2 pi i c (lane + 64 j) / N),
+    //             c = 1 .. N/256 - 1: real parts, imaginary parts
+    const int dft_nc = g.N >= 512 ? g.N / 256 : 1;
+    std::vector<uint32_t> dftc((size_t)(10 + 2 * (dft_nc - 1)) * 64 * 4);
     {
         const double PI = 3.14159265358979323846;
         for (int lane = 0; lane < 64; ++lane) {
@@ -345,6 +350,12 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
                 const float twr = (float)std::cos(ang), twi = (float)std::sin(ang);
                 std::memcpy(&dftc[((size_t)8 * 64 + lane) * 4 + j], &twr, 4);
                 std::memcpy(&dftc[((size_t)9 * 64 + lane) * 4 + j], &twi, 4);
+                for (int c = 1; c < dft_nc; ++c) {
+                    const double a2 = -2.0 * PI * (double)((c * (lane + 64 * j)) % g.N) / (double)g.N;
+                    const float t2r = (float)std::cos(a2), t2i = (float)std::sin(a2);
+                    std::memcpy(&dftc[((size_t)(10 + 2 * (c - 1)) * 64 + lane) * 4 + j], &t2r, 4);
+                    std::memcpy(&dftc[((size_t)(11 + 2 * (c - 1)) * 64 + lane) * 4 + j], &t2i, 4);
+                }
             }
         }
     }

@@ -32,7 +32,7 @@ struct wofdm_kdump {          // device pointers, all may be null
 template <int N> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
-    static constexpr int TW_BYTES = N == 256 ? 8 * 64 * 16 : 8 * N;
+    static constexpr int TW_BYTES = N == 256 || N == 512 ? 8 * 64 * 16 : 8 * N;
     static constexpr int off_g = off_tw + TW_BYTES;
     static constexpr int off_sums = off_g + 8 * N;
     static constexpr int off_flags = off_sums + 4 * 64;
@@ -57,8 +57,8 @@ struct wofdm_kparams {
     uint64_t items_q, items_r;     // (cell, frame) items per workgroup: q, and one more for the first r
     uint32_t seed_lo, seed_hi;
     unsigned long long *counts;   // [cells][4], entry 0 = cell inject_base_cell
-    // layouts 10 / 11 (both 256-point transforms on the matrix pipe): operand table [10][64] x 16 bytes (wofdm_abi.hip,
-    // build_dftc) and the power of two per (snr, channel) that centres the received samples in the f16 range
+    // layouts 10 / 11 / 12 (both transforms on the matrix pipe): operand table [10 + 2 (N/256 - 1)][64] x 16 bytes
+    // (wofdm_abi.hip) and the power of two per (snr, channel) that centres the received samples in the f16 range
     const uint4 *dftc;
     const float *rx_scale;
     const uint8_t *labels;  // inject: [cells][frames][S][N]
@@ -99,19 +99,21 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // 8 = one symbol per wave with the FIR on the matrix pipe (N >= 512; wofdm_fir8_tiles tiles per wave)
 // 10 / 11 = 6 / 7 with both 256-point transforms on the matrix pipe as well (lane l holds elements l + 64 j of each of the
 // wave's four symbols)
+// 12 = 8 with both transforms on the matrix pipe as well (N = 512, 1024: 16 . 16 . N/256, the last stage in registers)
 static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11; }
-static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 8) || wofdm_is_mdft(spw); }
+static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 12; }
+static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 8) || wofdm_is_mdft(spw) || spw == 12; }
 static inline int wofdm_firm_tiles(int spw) { return (spw == 7 || spw == 11) ? 10 : 9; }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
 #define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
 static inline int wofdm_rb(int n_fft, int spw = 1)
 {
-    if (spw == 8) return 2 * wofdm_fir8_tiles(n_fft);
+    if (wofdm_is_fir8(spw)) return 2 * wofdm_fir8_tiles(n_fft);
     if (wofdm_is_firm(spw)) return 2 * wofdm_firm_tiles(spw);
     return spw == 1 ? n_fft / 64 + 1 : (spw == 5 ? 20 : spw * (n_fft / 64) + 2);
 }
-static inline int wofdm_nsym(int spw) { return spw == 8 ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw); }
+static inline int wofdm_nsym(int spw) { return wofdm_is_fir8(spw) ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw); }
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
@@ -130,7 +132,7 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
     // one symbol per wave, matrix-pipe FIR: 16-byte operand rows must not straddle a symbol (B % 4)
-    if (firm && plain && n_fft >= 512 && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return 8;
+    if (firm && plain && n_fft >= 512 && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
@@ -145,14 +147,14 @@ static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
 // and zeros up to the end of the tile that covers the trailing samples behind the last wave.
 static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
-    if (spw == 8) return (8 + 2 * S * B + 2 * WOFDM_FIR8_VT) / 2;
+    if (wofdm_is_fir8(spw)) return (8 + 2 * S * B + 2 * WOFDM_FIR8_VT) / 2;
     if (wofdm_is_firm(spw))
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = (N == 256 ? 8 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int fixed = (N == 256 || N == 512 ? 8 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
     return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
 }
