@@ -219,8 +219,9 @@ def main():
                          "flop_per_symbol": fs,
                          "note": "achieved = algorithmic fp32 flop (SURVEY.md 8d F_sym x symbols) / kernel time, "
                                  "against the fp32 vector peak 157.3 TFLOP/s (= the fp32 MFMA dense peak). VALU issue "
-                                 "is the binding pipe (RNG, FFTs, mapping); the 21-tap FIR -- 64 % of F_sym -- runs on "
-                                 "the matrix pipe as a 3-term f16-split block-Toeplitz product with fp32 accumulation. "
+                                 "is the binding pipe (RNG, mapping, window and f16-split work); the 21-tap FIR -- 64 % "
+                                 "of F_sym -- and both 256-point transforms -- 27 % -- run on the matrix pipe as 3-term "
+                                 "f16-split products with fp32 accumulation (block-Toeplitz FIR, two 16x16 DFT stages). "
                                  "HBM is not the bound: generate mode reads constants and writes counters only "
                                  "(traffic = PMC bytes per launch, null when not measured on these sources)."},
             "ber": ber, "snr_db": SNR_DB.tolist(),

@@ -103,7 +103,12 @@ int wofdm_plan_destroy(wofdm_plan *plan);
 
 /* Asynchronous launch on `stream` (a hipStream_t, NULL = default stream): simulate frames
  * [frame_offset, frame_offset+frames_per_cell) of every cell with the on-device Philox4x32-10
- * streams and add into counts_dev[cells][4] (uint64, device memory of the plan's GPU). */
+ * streams and add into counts_dev[cells][4] (uint64, device memory of the plan's GPU).
+ * One frame kernel runs at a time per device: a launch waits (on the device, through an event) for the
+ * previous launch this process made on that GPU, whatever plan or stream it belonged to -- the kernels with
+ * the transforms on the matrix pipe must not share a SIMD with the others (wofdm_kernel.hip, mma33), and
+ * one launch fills the GPU anyway.  Other PROCESSES must not run these kernels on the same GPU at the same
+ * time (one process per GPU, as bench.py and distributed.py do). */
 int wofdm_plan_launch(wofdm_plan *plan, uint64_t frame_offset, uint64_t frames_per_cell,
                       uint64_t *counts_dev, void *stream);
 

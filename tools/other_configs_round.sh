@@ -3,8 +3,10 @@ TAG=${1:-r02}
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/${TAG}_other_configs.txt
 {
-echo "## tools/bench_configs.py --c4-full (HIP-event time of one launch per config; layouts 6/7/8 = matrix-pipe FIR)"
+echo "## tools/bench_configs.py --c4-full (HIP-event time of one launch per config; layouts 10/11/12 = FIR and both transforms on the matrix pipe)"
 timeout -k 10 300 python tools/bench_configs.py --c4-full 2>&1 | grep -v amdgpu.ids
+echo; echo "## the same with the plan option dft_valu = 1 (round-2 layouts 6/7/8: FIR on the matrix pipe, transforms on the VALU)"
+WOFDM_OPTS=dft_valu=1 timeout -k 10 300 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids
 echo; echo "## the same with WOFDM_FIR_VALU=1 (round-1 layouts: FIR on the VALU)"
 WOFDM_FIR_VALU=1 timeout -k 10 300 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids
 echo; echo "## tools/bench_inject.py (injected randomness streamed from HBM)"

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -204,8 +205,22 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
 #endif
     void *args[] = {&kp, &pl->d_wtx, &pl->d_wrx, &pl->d_h, &pl->d_nlin, &pl->d_geo, &pl->d_amask, &tm,
                     &pl->d_fira};
-    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                            dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), args, kp.lds_bytes, stream));
+    // One frame kernel at a time per device, whatever streams the callers use: the kernels of layouts 10 / 11 / 12 issue MFMAs
+    // in a rhythm that corrupts op_sel-swizzled packed arithmetic of OTHER waves on their SIMDs (wofdm_kernel.hip, mma33);
+    // they hold no such instruction themselves, every other kernel of the library does.  Each launch waits for the
+    // previous launch of this process on the device (an event; free when it is the same stream) -- a kernel fills the GPU
+    // on its own, so nothing is lost.
+    {
+        static std::mutex mu;
+        static hipEvent_t last[64] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        const int dev = pl->device & 63;
+        if (last[dev]) HIP_TRY(hipStreamWaitEvent(stream, last[dev], 0));
+        else HIP_TRY(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
+        HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
+                                dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), args, kp.lds_bytes, stream));
+        HIP_TRY(hipEventRecord(last[dev], stream));
+    }
     return WOFDM_OK;
 }
 
@@ -857,6 +872,7 @@ int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, cons
             hipMemcpy(d_h, hp.data(), hp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(WOFDM_E_HIP, "upload failed"); break;
         }
+        (void)hipDeviceSynchronize();      // (no frame kernel of this process beside these kernels: see launch())
         hipError_t e = hipErrorInvalidValue;
         if (g.N == 64) e = wofdm_interf_launch_n64(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
         if (g.N == 128) e = wofdm_interf_launch_n128(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
@@ -905,6 +921,7 @@ int wofdm_tx_psd(const wofdm_cfg *cfg, int device, const float *w_tx, const floa
             hipMemset(d_x, 0, (size_t)len * 8) != hipSuccess) {
             rc = fail(WOFDM_E_HIP, "upload failed"); break;
         }
+        (void)hipDeviceSynchronize();      // (no frame kernel of this process beside these kernels: see launch())
         hipError_t e = hipErrorInvalidValue;
         if (N == 64) e = wofdm_psd_launch_n64(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);
         if (N == 128) e = wofdm_psd_launch_n128(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);

@@ -16,8 +16,8 @@ struct wofdm_kdump {          // device pointers, all may be null
 };
 
 // LDS carve: fixed-size regions first (compile-time offsets), the frame buffer last.
-//   tw    float2[N]          twiddles exp(-2 pi i m / N)    (N = 256: 8 KB -- the matrix-pipe DFT layouts 10 / 11 keep
-//                            eight of the ten operand rows of the transforms there, [8][64] 16-byte rows)
+//   tw    float2[N]          twiddles exp(-2 pi i m / N)    (N = 256, 512: 6 KB -- the matrix-pipe layouts 10 / 11 / 12 keep
+//                            six of the ten operand rows of the transforms there, [6][64] 16-byte rows)
 //   g     float2[N]          pilot equaliser X0/Y0
 //   sums  float [2][32]      per-wave signal / noise power partials, double-buffered by frame parity
 //   flags int   [64]         [w] = last loop iteration whose phase A wave w has finished,
@@ -32,7 +32,7 @@ struct wofdm_kdump {          // device pointers, all may be null
 template <int N> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
-    static constexpr int TW_BYTES = N == 256 || N == 512 ? 8 * 64 * 16 : 8 * N;
+    static constexpr int TW_BYTES = N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N;
     static constexpr int off_g = off_tw + TW_BYTES;
     static constexpr int off_sums = off_g + 8 * N;
     static constexpr int off_flags = off_sums + 4 * 64;
@@ -154,7 +154,7 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 }
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = (N == 256 || N == 512 ? 8 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int fixed = (N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
     return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
 }

@@ -657,7 +657,7 @@ __device__ __forceinline__ v2f wfma(v2f x, float w, v2f acc)
     return mk(a, b);
 }
 // the wave's constants of the two stages: operand rows of th^(..) for real / imaginary outputs, hi / lo halves, and the
-// inter-stage twiddles (table: wofdm_abi.hip, build_dftc; rows 0..3 and 8, 9 sit in LDS, 4..7 come from L2)
+// inter-stage twiddles (table: wofdm_abi.hip; rows 0..3 and 8, 9 sit in LDS, 4..7 come from L2)
 struct mdft_consts { h8 brh, brl, bih, bil, arh, arl, aih, ail; f4 twr, twi; };
 // (t_re + i t_im) *= (twr + i twi), element-wise on the lane's four values
 __device__ __forceinline__ void mdft_twiddle(f4 &tr, f4 &ti, f4 wr, f4 wi)
@@ -1074,15 +1074,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     if (tid < 64) sums[tid] = 0.f;                 // (waves a short frame does not have leave their partial sums at zero)
     int iter = 0;                                  // frames this workgroup has started
     if constexpr (MPIPE) {
-        // rows 0..3 (stage-1 operands), 4, 6 (hi halves of the stage-2 operands) and 8, 9 (twiddles) of the operand
-        // table, [8][64] 16-byte rows; rows 5, 7 (the lo halves of stage 2, the last ones a transform needs) come from L2,
-        // requested at the start of the phase
+        // rows 0..3 (stage-1 operands) and 8, 9 (twiddles) of the operand table, [6][64] 16-byte rows; rows 4..7 (stage 2,
+        // which a transform needs last) come from L2, requested at the start of the phase (all ten in LDS would cost the
+        // structures with the longest strides their third workgroup per CU)
         u4 *dl = reinterpret_cast<u4 *>(smem + L::off_tw);
         const u4 *dg = reinterpret_cast<const u4 *>(p.dftc);
-        for (int i = tid; i < 8 * 64; i += blockDim.x) {
-            const int r = i >> 6, src = r < 4 ? r : (r == 4 ? 4 : (r == 5 ? 6 : r + 2));
-            dl[i] = dg[64 * src + (i & 63)];
-        }
+        for (int i = tid; i < 6 * 64; i += blockDim.x) dl[i] = dg[i < 256 ? i : i + 256];
     } else if constexpr (QW) fill_twiddles_qw(tw, tid, (int)blockDim.x);
     else fill_twiddles<N>(tw, tid, (int)blockDim.x);
     // constellation table: qammod(label) (Gray, unit average power; m:248-249)
@@ -1253,11 +1250,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             t2r[0] = t2i[0] = (f4){0.f, 0.f, 0.f, 0.f};
         };
         (void)mdft_tw2;
-        struct mdft_early { u4 arl, ail; };
-        auto mdft_request = [&]() {                     // the two rows that come from L2: asked for early in the phase
+        struct mdft_early { u4 arh, arl, aih, ail; };
+        auto mdft_request = [&]() {                     // the four rows that come from L2: asked for early in the phase
             mdft_early e;
-            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + lane;
-            e.arl = dg[5 * 64]; e.ail = dg[7 * 64];
+            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + 256 + lane;
+            e.arh = dg[0]; e.arl = dg[64]; e.aih = dg[128]; e.ail = dg[192];
             return e;
         };
         auto mdft_load = [&](const mdft_early &e) {
@@ -1265,9 +1262,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const u4 *dl = reinterpret_cast<const u4 *>(smem + L::off_tw) + lane;
             c.brh = __builtin_bit_cast(h8, dl[0]); c.brl = __builtin_bit_cast(h8, dl[64]);
             c.bih = __builtin_bit_cast(h8, dl[128]); c.bil = __builtin_bit_cast(h8, dl[192]);
-            c.arh = __builtin_bit_cast(h8, dl[256]); c.aih = __builtin_bit_cast(h8, dl[320]);
-            c.twr = __builtin_bit_cast(f4, dl[384]); c.twi = __builtin_bit_cast(f4, dl[448]);
-            c.arl = __builtin_bit_cast(h8, e.arl); c.ail = __builtin_bit_cast(h8, e.ail);
+            c.twr = __builtin_bit_cast(f4, dl[256]); c.twi = __builtin_bit_cast(f4, dl[320]);
+            c.arh = __builtin_bit_cast(h8, e.arh); c.arl = __builtin_bit_cast(h8, e.arl);
+            c.aih = __builtin_bit_cast(h8, e.aih); c.ail = __builtin_bit_cast(h8, e.ail);
             return c;
         };
         (void)mdft_load; (void)mdft_request;
