@@ -168,9 +168,52 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
     assert err["matrix pipe"][4] <= 3e-7 and err["valu"][4] <= 3e-7, err        # rms: both at the fp32 rounding floor of the dumps
 
 
+@pytest.mark.parametrize("system,n_fft,cp,k", [("wtx", 256, 32, 4), ("CPW", 256, 32, 6), ("WOLA", 512, 32, 4), ("WOLA", 1024, 32, 6)])
+def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
+    """The transforms (dftmtx(N)'/N and dftmtx(N), main_BER_calculation.m:370, 306) of one injected frame against the fp64 oracle:
+    on the matrix pipe (layouts 10 / 11 / 12: two 16 x 16 DFT stages as three-term split-f16 MFMA products, fp32 accumulation
+    and twiddles) and on the VALU (layouts 6 / 7 / 8, plan option dft_valu).  `tx` isolates the inverse transform (its input
+    is exact), `Y` against the fp64 DFT of the kernel's OWN received blocks the forward one.  Error over the stage's rms:
+    bounds 2e-6 (max) and 3e-7 (rms) for either form -- both sit at the fp32 rounding floor."""
+    S, seed, frame, cell = 16, 5, 99, 1
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[20:22].astype(np.complex64)
+    snrs = np.array([18.0], np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 2, 1, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True)
+    lab, noise = O.gen_labels(osys, seed, cell, frame), O.gen_noise(osys, seed, cell, frame)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h[1].astype(np.complex128), float(snrs[0]),
+                     lab, noise, dump=True)
+    err = {}
+    for name, valu in (("matrix pipe", 0), ("valu", 1)):
+        with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+            plan.set_option("dft_valu", valu)
+            layout = plan.kernel_id()[0]
+            assert (layout in (10, 11, 12)) == (valu == 0), layout
+            gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
+        e_tx = np.abs(gd["tx"] - od["tx"]) / np.sqrt(np.mean(np.abs(od["tx"]) ** 2))
+        # forward transform alone: the oracle's Rx stage (window, fold, shift, DFT) applied in fp64 to the kernel's own rx
+        rx = gd["rx"][:S * st.stride].astype(np.complex128).reshape(S, st.stride)
+        m = np.arange(n_fft + st.tail_rx)
+        z = np.zeros((S, n_fft), np.complex128)
+        np.add.at(z, (slice(None), m % n_fft), rx[:, st.prefix_rm + m] * w_rx.astype(np.float64)[m])
+        z = np.roll(z, -(st.circ_shift + st.tail_rx // 2), axis=1)
+        own = np.fft.fft(z, axis=1)
+        e_y = np.abs(gd["Y"] - own) / np.sqrt(np.mean(np.abs(own) ** 2))
+        err[name] = (layout, float(e_tx.max()), float(np.sqrt(np.mean(e_tx ** 2))), float(e_y.max()), float(np.sqrt(np.mean(e_y ** 2))))
+    print("\ntransforms vs fp64, %s N=%d cp=%d: " % (system, n_fft, cp)
+          + "; ".join("%s (layout %d): IDFT max %.2e rms %.2e, DFT alone max %.2e rms %.2e of the stage's rms" % ((n,) + err[n])
+                      for n in err))
+    for n in err:
+        assert err[n][1] <= 2e-6 and err[n][3] <= 2e-6, err
+        assert err[n][2] <= 3e-7 and err[n][4] <= 3e-7, err
+
+
 @pytest.mark.parametrize("system,n_fft,cp,k,opts", [("wtx", 256, 32, 4, {}), ("CPW", 256, 32, 6, {}), ("WOLA", 512, 32, 4, {}),
                                                      ("WOLA", 1024, 32, 6, {}), ("WOLA", 128, 16, 4, {}),
-                                                     ("wtx", 256, 32, 4, {"fir_valu": 1}), ("WOLA", 512, 32, 2, {"fir_valu": 1})])
+                                                     ("wtx", 256, 32, 4, {"fir_valu": 1}), ("WOLA", 512, 32, 2, {"fir_valu": 1}),
+                                                     ("wtx", 256, 32, 4, {"dft_valu": 1}), ("WOLA", 1024, 32, 6, {"dft_valu": 1})])
 def test_production_and_instrumented_kernels_count_the_same(channels, system, n_fft, cp, k, opts):
     """The stage-by-stage parity runs the instrumented instantiations (stage stores, barriers between the phases); the same
     injected frames through the PRODUCTION instantiation of the same layout must give the same error counters (the two
