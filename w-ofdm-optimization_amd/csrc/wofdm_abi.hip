@@ -128,8 +128,7 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
-    // (layout 12 -- N >= 512 with the transforms on the matrix pipe -- is built without the allocation variant)
-    const bool mdft = !pl->dft_valu && !(var == WOFDM_VAR_ALLOC && g.N >= 512);
+    const bool mdft = !pl->dft_valu;
     int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
     if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
@@ -482,12 +481,15 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
     HIP_TRY(hipSetDevice(pl->device));
     HIP_TRY(hipDeviceSynchronize());           // no launch of this plan may still read the mask
     const int N = pl->g.N, NQ = N / 4;
+    const size_t amask_words = (size_t)NQ + (size_t)(NQ > 256 ? NQ : 256);
     int nact = N;
     if (active) {
         nact = 0;
         // [0, NQ): word j, byte r <-> subcarrier j + r NQ; [NQ, 2 NQ): the quarter-wave order of
         // the N = 256 kernels, word 16 q + l, byte r <-> subcarrier l + 16 (q + 4 r)
-        std::vector<uint32_t> words((size_t)2 * NQ, 0u);
+        // N >= 512, [NQ, NQ + 256): the input element order of layout 12, word lane + 64 j, byte c <-> subcarrier
+        // N/16 (lane / 16 + 4 j) + NC (lane % 16) + c, NC = N / 256
+        std::vector<uint32_t> words(amask_words, 0u);
         for (int n = 0; n < N; ++n) {
             if (active[n]) { ++nact; continue; }
             words[(size_t)(n % NQ)] |= 0x80u << (8 * (n / NQ));
@@ -495,12 +497,17 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
                 const int l = n & 15, t = n >> 4;
                 words[(size_t)(NQ + 16 * (t & 3) + l)] |= 0x80u << (8 * (t >> 2));
             }
+            if (N >= 512) {
+                const int nc = N / 256, a = n / (N / 16), r = n % (N / 16), b = r / nc, c = r % nc;   // n = N/16 a + NC b + c
+                const int lane = 16 * (a & 3) + b, j = a >> 2;                                         // a = g + 4 j
+                words[(size_t)(NQ + lane + 64 * j)] |= 0x80u << (8 * c);
+            }
         }
         if (nact == 0) return fail(WOFDM_E_INVALID, "allocation loads no subcarrier");
-        if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, (size_t)2 * NQ * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(pl->d_amask, words.data(), (size_t)2 * NQ * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!pl->d_amask) HIP_TRY(hipMalloc(&pl->d_amask, amask_words * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->d_amask, words.data(), amask_words * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (!active && pl->d_amask) HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)2 * NQ * sizeof(uint32_t)));
+    if (!active && pl->d_amask) HIP_TRY(hipMemset(pl->d_amask, 0, amask_words * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_NACT, &nact, sizeof(int), hipMemcpyHostToDevice));
     pl->has_alloc = active && nact < N;
     return configure(pl);
@@ -564,8 +571,9 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
         HIP_TRY(hipMemcpy(pl->d_tspec, spec.data(), (size_t)MF * sizeof(float2), hipMemcpyHostToDevice));
     }
     if (!pl->d_amask) {        // the mask kernels always read an allocation word
-        HIP_TRY(hipMalloc(&pl->d_amask, (size_t)2 * NQ * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(pl->d_amask, 0, (size_t)2 * NQ * sizeof(uint32_t)));
+        const size_t amask_words = (size_t)NQ + (size_t)(NQ > 256 ? NQ : 256);
+        HIP_TRY(hipMalloc(&pl->d_amask, amask_words * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(pl->d_amask, 0, amask_words * sizeof(uint32_t)));
     }
     const bool had = pl->has_mask;
     pl->has_mask = true;

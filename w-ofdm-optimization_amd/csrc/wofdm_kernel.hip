@@ -989,7 +989,6 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : ((LAY == 7 || LAY == 11) ? 10 : 9), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
     static_assert(!FIR8 || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
-    static_assert(!MD8 || VAR == 0, "layout 12 is built without the allocation variant");
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -1373,6 +1372,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     w = bw[bit >> 5] >> (bit & 31u);
                 }
                 labi[j] = 0;
+                // byte c of the word: 0x80 when subcarrier n0 + c is NOT loaded (third part of the table: this layout's order);
+                // the flag rides in the label byte down to phase D
+                uint32_t am = 0;
+                if constexpr (ALLOC) am = g_amask[NQ + lane + 64 * j] & 0x80808080u;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     uint32_t Lb;
@@ -1380,12 +1383,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     else Lb = (w >> (c * ks)) & lmask;
                     labi[j] |= Lb << (8 * c);
                     xw[c][j] = qlw[Lb];
+                    if constexpr (ALLOC) {
+                        if ((am >> (8 * c)) & 0x80u) xw[c][j] = 0u;
+                    }
                     if (DUMP) {
                         const hpair hw = __builtin_bit_cast(hpair, xw[c][j]);
                         if (p.dump.labels_tx) p.dump.labels_tx[s * N + n0 + c] = (uint8_t)Lb;
                         if (p.dump.X) p.dump.X[s * N + n0 + c] = make_float2((float)hw.y * qscale, (float)hw.x * qscale);
                     }
                 }
+                if constexpr (ALLOC) labi[j] |= am;
             }
             // ... and once through the (still unused) row into OUTPUT element order for phase D: NC label bytes per (j) at
             // byte n0, read back one byte per output element
@@ -2591,7 +2598,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const hpair hw = __builtin_bit_cast(hpair, qlw[(labo[kc] >> (8 * j)) & lmask]);
-                        const float x0r = (float)hw.y, x0i = (float)hw.x;
+                        float x0r = (float)hw.y, x0i = (float)hw.x;
+                        if constexpr (ALLOC) {
+                            if ((labo[kc] >> (8 * j)) & 0x80u) { x0r = 0.f; x0i = 0.f; }      // G = 0 there
+                        }
                         const float y0r = yr[kc][j], y0i = yi[kc][j];
                         const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
                         gr[j] = (x0r * y0r + x0i * y0i) * inv;
@@ -2808,7 +2818,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     constexpr uint32_t LM = lmask * 0x01010101u;
                     const uint32_t cw = (iw << half) | qw;
                     const uint32_t gw = cw ^ ((cw >> 1) & GM);
-                    const uint32_t diff = (gw ^ labo[kc]) & LM;
+                    uint32_t diff = (gw ^ labo[kc]) & LM;
+                    if constexpr (ALLOC) diff &= ~(((labo[kc] >> 7) & 0x01010101u) * 0xFFu);   // bit 7 = not loaded: not counted
                     be_f += __popc(diff);
                     se_f += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
                     if (DUMP && p.dump.labels_rx) {
@@ -3216,7 +3227,8 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
     }
     if constexpr (N >= 512) {
-        if (spw == 12 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 12, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 12 && var <= WOFDM_VAR_ALLOC)
+            return var ? pick_mode<N, K, 12, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 12, WOFDM_VAR_PLAIN>(mode);
         if (spw == 8 && var <= WOFDM_VAR_ALLOC)
             return var ? pick_mode<N, K, 8, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 8, WOFDM_VAR_PLAIN>(mode);
     }
