@@ -162,8 +162,10 @@ int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
 
 /* Which instantiation of the frame kernel the plan launches: {layout id, variant}.  Layout: 1, 2 =
  * one / two symbols per wave with the FIR on the VALU; 4, 5 = four symbols per wave (N = 256), FIR on
- * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 10, 11 = 6, 7 with both 256-point transforms on
- * the matrix pipe as well; 8 = one symbol per wave (N >= 512), FIR on the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
+ * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 9 = one symbol per wave with the FIR on the matrix pipe (Tx-mask
+ * variants); 10, 11 = 6, 7 with both 256-point transforms on
+ * the matrix pipe as well; 8 = one symbol per wave (N >= 512), FIR on the matrix pipe; 12 = 8 with both transforms on the
+ * matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
  * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
 int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
 

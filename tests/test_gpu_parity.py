@@ -573,7 +573,11 @@ def _geometry_for(n_fft, layout, var):
         if n_fft >= 512:
             env["fir_valu"] = 1
             return "WOLA", 32, 16, env
+        if var >= 2:
+            env["fir_valu"] = 1                                                   # (else the masked variants run layout 9)
         return ("wtx", 32 if n_fft == 256 else 16, 16 if var >= 2 else 9, env)   # a mask forces one symbol per wave
+    if layout == 9:                                                               # Tx mask + matrix-pipe FIR: strides 4 | B, B >= N
+        return ("wtx" if n_fft >= 256 else "WOLA"), 32 if n_fft >= 256 else 16, 16, env
     if layout == 2:
         env.update(fir_valu=1, max_spw=2)
         return "wtx", 32 if n_fft == 256 else 16, 16, env

@@ -129,7 +129,7 @@ int configure(wofdm_plan *pl)
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
     const bool mdft = !pl->dft_valu;
-    int spw = masked ? 1 : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
+    int spw = masked ? wofdm_spw_masked(g.N, g.B, firm) : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
     if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)

@@ -101,8 +101,10 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // wave's four symbols)
 // 12 = 8 with both transforms on the matrix pipe as well (N = 512, 1024: 16 . 16 . N/256, the last stage in registers)
 static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11; }
-static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 12; }
-static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 8) || wofdm_is_mdft(spw) || spw == 12; }
+// 9 = one symbol per wave, FIR on the matrix pipe, for the Tx-mask variants (any N <= 512): layout 8's frame format; the mask
+// stage works on the rows as fp32, phase B turns them into the f16 planes in place
+static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw == 12; }
+static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12; }
 static inline int wofdm_firm_tiles(int spw) { return (spw == 7 || spw == 11) ? 10 : 9; }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
@@ -134,6 +136,12 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
     // one symbol per wave, matrix-pipe FIR: 16-byte operand rows must not straddle a symbol (B % 4)
     if (firm && plain && n_fft >= 512 && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
+}
+
+// layout of the Tx-mask variants: 9 where the matrix-pipe FIR fits (16-byte operand rows must not straddle a symbol), else 1
+static inline int wofdm_spw_masked(int n_fft, int B, bool firm)
+{
+    return (firm && B >= n_fft && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) ? 9 : 1;
 }
 
 // float2 elements of noise scratch per workgroup (0: not used for this DFT length)

@@ -945,7 +945,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = (LAY == 8 || LAY == 12) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? ((LAY == 7 || LAY == 11) ? 20 : 18)
+    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? ((LAY == 7 || LAY == 11) ? 20 : 18)
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -966,7 +966,7 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int LAY, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__((LAY == 8 || LAY == 12) ? 1024 : (LAY >= 4 ? 256 : 1024 / LAY), (LAY >= 4 && LAY != 8 && LAY != 12) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__((LAY == 8 || LAY == 9 || LAY == 12) ? 1024 : (LAY >= 4 ? 256 : 1024 / LAY), (LAY >= 4 && LAY != 8 && LAY != 9 && LAY != 12) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
@@ -984,11 +984,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool MD8 = LAY == 12;
     constexpr bool MPIPE = MDFT || MD8;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
     constexpr int NC = MD8 ? N / 256 : 1;
-    constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT, FIR8 = LAY == 8 || MD8, FIRM = FIRQ || FIR8;
+    // layout 9: the Tx-mask variants with the FIR on the matrix pipe -- layout 8's frame format; the windowed symbols and the
+    // mask stage live in the rows as fp32, phase B converts each row to the two f16 planes in place
+    constexpr bool FIR8M = LAY == 9;
+    constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT, FIR8 = LAY == 8 || MD8 || FIR8M, FIRM = FIRQ || FIR8;
     constexpr int SPW = FIR8 ? 1 : (LAY >= 5 ? 4 : LAY);     // symbols per wave
     constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : ((LAY == 7 || LAY == 11) ? 10 : 9), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
-    static_assert(!FIR8 || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
+    static_assert(!FIR8 || FIR8M || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
+    static_assert(!FIR8M || VAR >= 2, "layout 9 is the Tx-mask variants' matrix-pipe FIR layout");
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -1581,7 +1585,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int Bs = (s == S - 1) ? 0x3fffffff : B;
                 // tailb + s TS - (fb + B) in v2f units, from the LDS offsets (a pointer
                 // difference would be taken on 64-bit generic addresses)
-                const int Dt = tail_off + s * TS - (LT - 1) - (s + 1) * B;
+                // (layout 9: row s starts 4 v2f into the buffer -- 8 zero words -- instead of LT - 1)
+                const int Dt = tail_off + s * TS - (FIR8M ? 4 : LT - 1) - (s + 1) * B;
 #pragma unroll
                 for (int q = 0; q < BPL; ++q) {
                     const int j = lane + 64 * q;
@@ -1603,7 +1608,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         };
-        if constexpr (FIR8) {
+        if constexpr (FIR8 && !FIR8M) {
             // one symbol per wave, rows of plane H and plane L side by side; the fall tail goes to the
             // tail planes, the last symbol's into the virtual row behind the frame
             const int s = s0;
@@ -1851,7 +1856,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int r = 0; r < 4; ++r) {
                     const int m = lane + 64 * q + r * MQ;
                     v2f xm = mk(0.f, 0.f);
-                    if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
+                    // (P <= N + CPCS_MAX: the elements behind that are zeros at compile time, which the first stage of the
+                    // transform folds away)
+                    if (64 * q + r * MQ < N + L::CPCS_MAX)
+                        if (m < P) xm = (m < B) ? fb[m] : xt[m - B];
                     y[0][q][r] = xm;
                 }
             fft_1024_half<-1>(y, scr, mtw, lane);
@@ -2010,7 +2018,51 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         h8 A[4];                                   // [2 half + part]: window half 0/1, h_hi / h_lo
 #pragma unroll
         for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(h8, fa[64 * a]);
-        if constexpr (FIR8) {
+        if constexpr (FIR8M) {
+            // Tx-mask variants: the row still holds the masked symbol as fp32 (own part and the predecessor's spill: both
+            // complete, barrier 1).  Overlap-add of the previous symbol's fall tail (m:253-259) in fp32, then the row --
+            // the same bytes -- becomes its two f16 planes in place; the last symbol's own fall tail, which sits behind its
+            // row, becomes the virtual row the trailing tile reads.  One more hand-over: the successor's first tile reaches
+            // back into this row's last samples (flags [48 + w], or a barrier in the instrumented kernels).
+            v2f *fb = reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0);
+            if (s0 > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s0 - 1) * beta + lane];
+            wave_sync();
+            constexpr int RQ = (N + L::CPCS_MAX + 63) / 64;
+            v2f xs[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int i = lane + 64 * q;
+                xs[q] = i < B ? fb[i] : mk(0.f, 0.f);
+            }
+            const bool lastsym = s0 == S - 1;
+            v2f xtl = mk(0.f, 0.f);
+            if (lastsym && lane < beta) xtl = fb[B + lane];
+            wave_sync();
+            uint32_t *hrow = Hp + 8 + 2 * B * s0;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int i = lane + 64 * q;
+                if (i < B) {
+                    uint32_t hi, lo;
+                    split_h(xs[q], hi, lo);
+                    hrow[i] = hi;
+                    hrow[B + i] = lo;
+                }
+            }
+            if (lastsym && lane < VT) {
+                uint32_t hi = 0, lo = 0;
+                if (lane < beta) split_h(xtl, hi, lo);
+                hrow[2 * B + lane] = hi;
+                hrow[2 * B + VT + lane] = lo;
+            }
+            wave_sync();
+            if constexpr (RELAXM) {
+                post_flag(&flags[48 + wv], iter, lane);
+                if (wv > 0) wait_flag(&flags[48 + wv - 1], iter, &flags[20]);
+            } else {
+                __syncthreads();
+            }
+        } else if constexpr (FIR8) {
             // overlap-add of the previous symbol's fall tail (m:253-259), in fp32, re-split
             if (s0 > 0 && lane < beta) {
                 uint32_t *hw = Hp + 8 + 2 * B * s0 + lane;
@@ -2103,7 +2155,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if (q0 + 16 < 0) { ph1 = z ? Hp : rh + q0 + 16 - B; pl1 = z ? Hp : rh + q0 + 16; }
                 }
                 o.h0 = ld16(ph0); o.h1 = ld16(ph1); o.l0 = ld16(pl0); o.l1 = ld16(pl1);
-                if (G == NT - 1 && !trailing) {
+                // (layout 9: a short row -- N < 512 -- can end in ANY tile, and the rows behind it may still hold fp32 data)
+                if ((FIR8M || G == NT - 1) && !trailing) {
                     // The block that holds the symbol's last samples may reach up to 4 samples past
                     // them (B is a multiple of 4, not of 8).  The Toeplitz entries that meet those are
                     // zero, but the words there are another row's (possibly the next wave's scratch:
@@ -2246,6 +2299,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // wave 0, the wave that reaches barrier 2 first; it reads behind the last wave's symbols
             if constexpr (RELAX) {
                 if (W > 1) wait_flag(&flags[W - 1], iter, &flags[20]);
+            }
+            if constexpr (FIR8M && RELAXM) {
+                if (W > 1) wait_flag(&flags[48 + W - 1], iter, &flags[20]);       // (the last row and its virtual row are planes)
             }
             const int jt = S * B;
             const bool v0 = jl < tail_total, v1 = jl + 1 < tail_total;
@@ -3223,6 +3279,15 @@ template <int N, int K, int SPW> wofdm_kernel_fn pick_var(int mode, int var)
 template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
 {
     if (spw == 1) return pick_var<N, K, 1>(mode, var);
+    if (spw == 9) {
+        if constexpr (N <= WOFDM_TXMASK_MAX_N) {
+            if (var == WOFDM_VAR_TXMASK) return pick_mode<N, K, 9, WOFDM_VAR_TXMASK>(mode);
+        }
+        if constexpr (N <= WOFDM_TXFFT_MAX_N) {
+            if (var == WOFDM_VAR_TXFFT) return pick_mode<N, K, 9, WOFDM_VAR_TXFFT>(mode);
+        }
+        return nullptr;
+    }
     if constexpr (N <= 256) {
         if (spw == 2) return pick_var<N, K, 2>(mode, var);
     }
