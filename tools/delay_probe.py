@@ -5,7 +5,7 @@ Needs the delay build (``bash tools/build_variant.sh delay "64 128 256 512 1024"
 For every delay point of the frame (DELAY_AT in wofdm_kernel.hip) and several sets of waves, the chosen
 waves sleep there for delay_len x 4 us; the counters must not change.
 
-    python tools/delay_probe.py [n_fft k [inject]]"""
+    python tools/delay_probe.py [n_fft k [inject [system]]]        (PROBE_MASK=1: with allocation + Tx mask)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +39,10 @@ if inject:
     dl = torch.from_numpy(labels).cuda()
     dn = torch.from_numpy(noise.view(np.float32).reshape(6, F, nl, 2)).cuda()
 with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+    if os.environ.get("PROBE_MASK") == "1":              # the Tx-mask variants (layout 9 / 1): half-band allocation + spectral mask
+        from wofdm_amd import channel_mask as CM
+        plan.set_allocation(CM.half_band_allocation(n_fft))
+        plan.set_tx_mask(CM.tx_mask(st.sym_len))
     nw = plan.info()["waves_per_workgroup"]
     print("N=%d k=%d %s inject=%d kernel %s F=%d waves %d" % (n_fft, k, system, inject, plan.kernel_id(), F, nw))
     def launch():
