@@ -165,7 +165,7 @@ int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
  * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 9 = one symbol per wave with the FIR on the matrix pipe (Tx-mask
  * variants); 10, 11 = 6, 7 with both 256-point transforms on
  * the matrix pipe as well; 8 = one symbol per wave (N >= 512), FIR on the matrix pipe; 12 = 8 with both transforms on the
- * matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
+ * matrix pipe; 13, 14 = N = 64 / 128, sixteen / eight symbols per wave, FIR and transforms on the matrix pipe.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
  * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
 int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
 

@@ -45,6 +45,11 @@ def test_device_present_and_philox_kat():
 def _expected_layout(st, n_fft, S):
     """Layout id wofdm_plan_create picks for a plain plan (wofdm_spw in csrc/wofdm_kernel.h)."""
     B = st.stride
+    if n_fft <= 128 and S % (1024 // n_fft) == 0 and B >= n_fft:
+        if (1024 // n_fft) * B <= 128 * 10:
+            return 13
+        if (1024 // n_fft) * B <= 128 * 11:
+            return 14
     if n_fft == 256 and S % 4 == 0 and B >= n_fft:
         if 4 * B <= 128 * 9:
             return 10
@@ -151,7 +156,7 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("fir_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (6, 7, 8, 10, 11, 12)) == (valu == 0), layout
+            assert (layout in (6, 7, 8, 10, 11, 12, 13, 14)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e = np.abs(gd["conv"] - od["conv"])
         # ... and the FIR alone: against the fp64 convolution of the kernel's OWN transmitted frame (the chain's error
@@ -168,11 +173,12 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
     assert err["matrix pipe"][4] <= 3e-7 and err["valu"][4] <= 3e-7, err        # rms: both at the fp32 rounding floor of the dumps
 
 
-@pytest.mark.parametrize("system,n_fft,cp,k", [("wtx", 256, 32, 4), ("CPW", 256, 32, 6), ("WOLA", 512, 32, 4), ("WOLA", 1024, 32, 6)])
+@pytest.mark.parametrize("system,n_fft,cp,k", [("wtx", 256, 32, 4), ("CPW", 256, 32, 6), ("WOLA", 512, 32, 4), ("WOLA", 1024, 32, 6),
+                                               ("wtx", 64, 16, 2), ("WOLA", 128, 32, 4)])
 def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
     """The transforms (dftmtx(N)'/N and dftmtx(N), main_BER_calculation.m:370, 306) of one injected frame against the fp64 oracle:
-    on the matrix pipe (layouts 10 / 11 / 12: two 16 x 16 DFT stages as three-term split-f16 MFMA products, fp32 accumulation
-    and twiddles) and on the VALU (layouts 6 / 7 / 8, plan option dft_valu).  `tx` isolates the inverse transform (its input
+    on the matrix pipe (layouts 10 ... 14: 16 x 16 DFT stages as three-term split-f16 MFMA products, fp32 accumulation
+    and twiddles) and on the VALU (layouts 2 / 6 / 7 / 8, plan option dft_valu).  `tx` isolates the inverse transform (its input
     is exact), `Y` against the fp64 DFT of the kernel's OWN received blocks the forward one.  Error over the stage's rms:
     bounds 2e-6 (max) and 3e-7 (rms) for either form -- both sit at the fp32 rounding floor."""
     S, seed, frame, cell = 16, 5, 99, 1
@@ -190,7 +196,7 @@ def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("dft_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (10, 11, 12)) == (valu == 0), layout
+            assert (layout in (10, 11, 12, 13, 14)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e_tx = np.abs(gd["tx"] - od["tx"]) / np.sqrt(np.mean(np.abs(od["tx"]) ** 2))
         # forward transform alone: the oracle's Rx stage (window, fold, shift, DFT) applied in fp64 to the kernel's own rx
@@ -213,7 +219,8 @@ def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
 @pytest.mark.parametrize("system,n_fft,cp,k,opts", [("wtx", 256, 32, 4, {}), ("CPW", 256, 32, 6, {}), ("WOLA", 512, 32, 4, {}),
                                                      ("WOLA", 1024, 32, 6, {}), ("WOLA", 128, 16, 4, {}),
                                                      ("wtx", 256, 32, 4, {"fir_valu": 1}), ("WOLA", 512, 32, 2, {"fir_valu": 1}),
-                                                     ("wtx", 256, 32, 4, {"dft_valu": 1}), ("WOLA", 1024, 32, 6, {"dft_valu": 1})])
+                                                     ("wtx", 256, 32, 4, {"dft_valu": 1}), ("WOLA", 1024, 32, 6, {"dft_valu": 1}),
+                                                     ("wtx", 64, 16, 2, {}), ("WOLA", 128, 32, 6, {})])
 def test_production_and_instrumented_kernels_count_the_same(channels, system, n_fft, cp, k, opts):
     """The stage-by-stage parity runs the instrumented instantiations (stage stores, barriers between the phases); the same
     injected frames through the PRODUCTION instantiation of the same layout must give the same error counters (the two

@@ -45,7 +45,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for system in W.SYSTEMS:
         run(system, 256, 4, 1, 1, 62500)
-    run("WOLA", 64, 2, 4, 5, f * 8)
+    run("WOLA", 64, 2, 4, 5, f * 8, cp=16)            # (C1 has CP 16)
     run("WOLA", 128, 4, 4, 5, f * 4)
     run("WOLA", 512, 4, 10, 20, f // 2)
     run("WOLA", 1024, 6, 100, 20, max(1, f // 20))

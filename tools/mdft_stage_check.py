@@ -4,7 +4,7 @@ import wofdm_amd as W
 from oracle import oracle as O
 ch = np.load(os.path.join(R, "tests", "golden", "channels_vehA.npz"))["h"]
 def rel(a,b): return float(np.abs(a-b).max()/np.abs(b).max())
-for system, n_fft, cp, k in [("wtx",256,32,4),("CPW",256,32,6),("WOLA",512,32,4),("CPwtx",512,32,4),("CPwrx",512,32,2),("wtx",512,64,4),("WOLA",1024,32,6),("CPwrx",1024,32,2),("WOLA",1024,64,4)]:
+for system, n_fft, cp, k in [("wtx",64,16,2),("WOLA",64,16,4),("CPW",64,16,6),("wrx",64,16,2),("WOLA",128,32,4),("wtx",128,16,6),("CPwrx",128,20,2),("wtx",64,64,2)]:
     S, seed, frame = 16, 11, 123456789012
     st = W.make_structure(system, n_fft, cp)
     w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)

@@ -128,9 +128,10 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
-    const bool mdft = !pl->dft_valu;
+    // (layouts 13 / 14 -- N = 64, 128 with the transforms on the matrix pipe -- are built without the allocation variant)
+    const bool mdft = !pl->dft_valu && !(var == WOFDM_VAR_ALLOC && g.N <= 128);
     int spw = masked ? wofdm_spw_masked(g.N, g.B, firm) : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
-    if (pl->max_spw > 0 && wofdm_nsym(spw) > pl->max_spw)
+    if (pl->max_spw > 0 && wofdm_nsym(spw, g.N) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
@@ -148,7 +149,7 @@ int configure(wofdm_plan *pl)
     }
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw), lds));
+        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw, g.N), lds));
     if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
     const int fbuf = wofdm_fbuf_len(g.N, g.T, spw, g.S, g.B);
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
@@ -217,7 +218,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         if (last[dev]) HIP_TRY(hipStreamWaitEvent(stream, last[dev], 0));
         else HIP_TRY(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                                dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw))), args, kp.lds_bytes, stream));
+                                dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw, pl->g.N))), args, kp.lds_bytes, stream));
         HIP_TRY(hipEventRecord(last[dev], stream));
     }
     return WOFDM_OK;
@@ -330,7 +331,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     //   rows 8, 9  the inter-stage twiddles exp(-2 pi i (4 g + j) a / 256), j < 4: real parts, imaginary parts (fp32)
     //   rows 10.. (N = 512, 1024: layout 12) the twiddles in front of the last, radix-N/256 stage, exp(-2 pi i c (lane + 64 j) / N),
     //             c = 1 .. N/256 - 1: real parts, imaginary parts
-    const int dft_nc = g.N >= 512 ? g.N / 256 : 1;
+    const int dft_nc = g.N >= 512 ? g.N / 256 : (g.N == 128 ? 2 : 1);   // (rows beyond the first ten: N >= 512, and N = 128)
     std::vector<uint32_t> dftc((size_t)(10 + 2 * (dft_nc - 1)) * 64 * 4);
     {
         const double PI = 3.14159265358979323846;
@@ -360,11 +361,20 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
                         dftc[((size_t)(4 * st + 2 * o + 1) * 64 + lane) * 4 + j] = wlo;
                     }
                 }
-                const double ang = -2.0 * PI * (double)((4 * gq + j) * a) / 256.0;
+                double ang = -2.0 * PI * (double)((4 * gq + j) * a) / 256.0;
+                // (N = 64, 128 -- layouts 13 / 14: ONE 16-point stage; rows 8, 9 (and 10, 11 at N = 128) hold the twiddles in front
+                // of the radix-N/16 stage, exp(-2 pi i (4 p + j) (lane % 16) / N), p = part of the symbol's N/16 stage-1 outputs)
+                if (g.N <= 128) ang = -2.0 * PI * (double)(j * a) / (double)g.N;
                 const float twr = (float)std::cos(ang), twi = (float)std::sin(ang);
                 std::memcpy(&dftc[((size_t)8 * 64 + lane) * 4 + j], &twr, 4);
                 std::memcpy(&dftc[((size_t)9 * 64 + lane) * 4 + j], &twi, 4);
-                for (int c = 1; c < dft_nc; ++c) {
+                if (g.N == 128) {
+                    const double a3 = -2.0 * PI * (double)((4 + j) * a) / 128.0;
+                    const float t3r = (float)std::cos(a3), t3i = (float)std::sin(a3);
+                    std::memcpy(&dftc[((size_t)10 * 64 + lane) * 4 + j], &t3r, 4);
+                    std::memcpy(&dftc[((size_t)11 * 64 + lane) * 4 + j], &t3i, 4);
+                }
+                for (int c = 1; g.N >= 512 && c < dft_nc; ++c) {
                     const double a2 = -2.0 * PI * (double)((c * (lane + 64 * j)) % g.N) / (double)g.N;
                     const float t2r = (float)std::cos(a2), t2i = (float)std::sin(a2);
                     std::memcpy(&dftc[((size_t)(10 + 2 * (c - 1)) * 64 + lane) * 4 + j], &t2r, 4);
@@ -627,7 +637,7 @@ int wofdm_plan_status(wofdm_plan *pl)
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
-    info[0] = pl->g.S / wofdm_nsym(pl->spw);
+    info[0] = pl->g.S / wofdm_nsym(pl->spw, pl->g.N);
     info[1] = (int32_t)pl->base.lds_bytes;
     info[2] = pl->cus * pl->occ;
     info[3] = pl->occ;

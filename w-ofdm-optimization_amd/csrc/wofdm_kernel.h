@@ -100,12 +100,15 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // 10 / 11 = 6 / 7 with both 256-point transforms on the matrix pipe as well (lane l holds elements l + 64 j of each of the
 // wave's four symbols)
 // 12 = 8 with both transforms on the matrix pipe as well (N = 512, 1024: 16 . 16 . N/256, the last stage in registers)
-static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11; }
+// 13 / 14 = N = 64, 128 with the FIR and both transforms on the matrix pipe: 16 / 8 symbols per wave (one MFMA stage over the stride-N/16
+// index, the radix-N/16 stage in registers), 10 / 11 FIR tiles per wave
+static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11 || spw == 13 || spw == 14; }
+static inline bool wofdm_is_small(int spw) { return spw == 13 || spw == 14; }
 // 9 = one symbol per wave, FIR on the matrix pipe, for the Tx-mask variants (any N <= 512): layout 8's frame format; the mask
 // stage works on the rows as fp32, phase B turns them into the f16 planes in place
 static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw == 12; }
 static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12; }
-static inline int wofdm_firm_tiles(int spw) { return (spw == 7 || spw == 11) ? 10 : 9; }
+static inline int wofdm_firm_tiles(int spw) { return spw == 14 ? 11 : ((spw == 7 || spw == 11 || spw == 13) ? 10 : 9); }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
 #define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
@@ -115,7 +118,11 @@ static inline int wofdm_rb(int n_fft, int spw = 1)
     if (wofdm_is_firm(spw)) return 2 * wofdm_firm_tiles(spw);
     return spw == 1 ? n_fft / 64 + 1 : (spw == 5 ? 20 : spw * (n_fft / 64) + 2);
 }
-static inline int wofdm_nsym(int spw) { return wofdm_is_fir8(spw) ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw); }
+static inline int wofdm_nsym(int spw, int n_fft = 256)
+{
+    if (wofdm_is_small(spw)) return 1024 / n_fft;           // 16 symbols per wave at N = 64, 8 at N = 128
+    return wofdm_is_fir8(spw) ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw);
+}
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
 // it (N <= 256) and S is even, else one.  WOFDM_MAX_SPW (developer switch) caps it.
@@ -127,6 +134,10 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
     // (the matrix-pipe kernels take a stride of at least n_fft for granted: their tiles below SPW n_fft
     // samples carry no validity tests)
     firm = firm && B >= n_fft;
+    if (WOFDM_MAX_SPW >= 4 && plain && mdft && firm && n_fft <= 128 && S % (1024 / n_fft) == 0) {
+        if ((1024 / n_fft) * B <= 128 * wofdm_firm_tiles(13)) return 13;
+        if ((1024 / n_fft) * B <= 128 * wofdm_firm_tiles(14)) return 14;
+    }
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return mdft ? 10 : 6;
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return mdft ? 11 : 7;
@@ -155,6 +166,8 @@ static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
 // and zeros up to the end of the tile that covers the trailing samples behind the last wave.
 static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
+    if (wofdm_is_small(spw))
+        return (WOFDM_FIRM_PRE + (S - wofdm_nsym(spw, N)) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     if (wofdm_is_fir8(spw)) return (8 + 2 * S * B + 2 * WOFDM_FIR8_VT) / 2;
     if (wofdm_is_firm(spw))
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;

@@ -712,6 +712,32 @@ __device__ __forceinline__ void mdft_big(const h8 (&xh)[NC], const h8 (&xl)[NC],
     }
 }
 
+// N = 16 C, C = 4 or 8 (layouts 13, 14): n = C a + c, k = ka + 16 kc.  ONE matrix stage over a (the same operand rows as stage 1 of
+// N = 256) with 16 (symbol, c) pairs as the rows of a set: lane (ka, g') receives, as the four elements of its accumulator, c = 4 p + j'
+// of symbol g' of the set's group (p = part: one set per group at C = 4, two at C = 8) -- the twiddle om_N^(c ka) and the radix-C
+// stage over c then run on the elements of ONE lane's registers, real and imaginary parts apart.
+// radix-4 over the four elements of (r, i): out element kc = sum_c in[c] (-i)^(c kc)
+__device__ __forceinline__ void radix4_elems(f4 &r, f4 &i)
+{
+    const float a0r = r.x + r.z, a0i = i.x + i.z, a1r = r.x - r.z, a1i = i.x - i.z;
+    const float a2r = r.y + r.w, a2i = i.y + i.w, a3r = r.y - r.w, a3i = i.y - i.w;
+    r = (f4){a0r + a2r, a1r + a3i, a0r - a2r, a1r - a3i};
+    i = (f4){a0i + a2i, a1i - a3r, a0i - a2i, a1i + a3r};
+}
+// radix-8 over (t0 = elements c = 0..3, t1 = c = 4..7): even outputs kc = 2 e in (r0, i0), odd outputs kc = 2 e + 1 in (r1, i1)
+__device__ __forceinline__ void radix8_elems(f4 &r0, f4 &i0, f4 &r1, f4 &i1)
+{
+    constexpr float h = 0.70710678118654752f;
+    const f4 er = r0 + r1, ei = i0 + i1, orr = r0 - r1, oi = i0 - i1;
+    // odd branch: times om_8^j = {1, (1 - i) h, -i, (-1 - i) h}
+    const f4 wr = {1.f, h, 0.f, -h}, wi = {0.f, -h, -1.f, -h};
+    f4 pr = orr * wr - oi * wi, pi = orr * wi + oi * wr;
+    r0 = er; i0 = ei;
+    radix4_elems(r0, i0);
+    radix4_elems(pr, pi);
+    r1 = pr; i1 = pi;
+}
+
 // registers -> (LDS stages) -> registers, natural order in and out, SPW symbols at once
 template <int N, int DIR, int SPW>
 __device__ __forceinline__ void fft_wave(v2f (&v)[SPW][geo<N>::BPL][4], v2f *fb, int sb, const v2f *tw,
@@ -945,7 +971,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? ((LAY == 7 || LAY == 11) ? 20 : 18)
+    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 14 ? 22 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 20 : 18))
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -966,7 +992,8 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int LAY, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__((LAY == 8 || LAY == 9 || LAY == 12) ? 1024 : (LAY >= 4 ? 256 : 1024 / LAY), (LAY >= 4 && LAY != 8 && LAY != 9 && LAY != 12) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__((LAY == 8 || LAY == 9 || LAY == 12) ? 1024 : ((LAY == 13 || LAY == 14) ? N : (LAY >= 4 ? 256 : 1024 / LAY)),
+                                   (LAY >= 4 && LAY != 8 && LAY != 9 && LAY != 12) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
@@ -982,14 +1009,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // registers; mdft_big): lane (b = lane % 16, g = lane / 16) holds the INPUT elements N/16 (g + 4 j) + NC b + c and the
     // OUTPUT elements lane + 64 j + 256 c, j < 4, c < NC
     constexpr bool MD8 = LAY == 12;
-    constexpr bool MPIPE = MDFT || MD8;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
+    // layouts 13, 14: N = 64 / 128, sixteen / eight symbols per wave, ONE matrix stage + the radix-N/16 stage in registers (radix4_elems)
+    constexpr bool MDS = LAY == 13 || LAY == 14;
+    constexpr int SC = N / 16, SCS = MDS ? SC / 4 : 1, SGR = 4 / SCS;      // elements per lane and symbol, sets per group, groups
+    constexpr bool MPIPE = MDFT || MD8 || MDS;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
     constexpr int NC = MD8 ? N / 256 : 1;
     // layout 9: the Tx-mask variants with the FIR on the matrix pipe -- layout 8's frame format; the windowed symbols and the
     // mask stage live in the rows as fp32, phase B converts each row to the two f16 planes in place
     constexpr bool FIR8M = LAY == 9;
-    constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT, FIR8 = LAY == 8 || MD8 || FIR8M, FIRM = FIRQ || FIR8;
-    constexpr int SPW = FIR8 ? 1 : (LAY >= 5 ? 4 : LAY);     // symbols per wave
-    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : ((LAY == 7 || LAY == 11) ? 10 : 9), PRE = WOFDM_FIRM_PRE;
+    constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT || MDS, FIR8 = LAY == 8 || MD8 || FIR8M, FIRM = FIRQ || FIR8;
+    constexpr int SPW = MDS ? 1024 / N : (FIR8 ? 1 : (LAY >= 5 ? 4 : LAY));     // symbols per wave
+    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 14 ? 11 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 10 : 9)), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
     static_assert(!FIR8 || FIR8M || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
     static_assert(!FIR8M || VAR >= 2, "layout 9 is the Tx-mask variants' matrix-pipe FIR layout");
@@ -1010,9 +1040,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool FULL = geo<N>::FULL;
     // SPW = 4: quarter-wave layout (fft_qw): 16 lanes per symbol, 16 subcarriers per lane, 4-wave
     // workgroups, three of them per CU at up to 168 VGPRs
-    constexpr bool QW = SPW == 4 && !MDFT;
+    constexpr bool QW = SPW == 4 && !MDFT && !MDS;
     static_assert(!(QW || MDFT) || (N == 256 && VAR <= 1), "the four-symbol layouts are built for N = 256 without Tx mask");
-    constexpr int VS = QW ? 1 : SPW, VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
+    static_assert(!MDS || ((N == 64 || N == 128) && VAR == 0), "layouts 13 / 14 are built for N = 64, 128, every subcarrier loaded");
+    constexpr int VS = QW ? 1 : (MDS ? 1 : SPW), VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, LAY>::RB, NBK = fir_geo<N, LAY>::NBK;
     constexpr bool EVEN = fir_geo<N, LAY>::EVEN;
     // Large DFTs would keep RB = N/64+1 noise samples AND FIR outputs per lane alive across
@@ -1076,7 +1107,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     if (tid < 64) flags[tid] = 0;
     if (tid < 64) sums[tid] = 0.f;                 // (waves a short frame does not have leave their partial sums at zero)
     int iter = 0;                                  // frames this workgroup has started
-    if constexpr (MPIPE) {
+    if constexpr (MDS) {
+        // (N = 64, 128: up to a dozen workgroups per CU -- the operand rows come from L2 in every phase)
+    } else if constexpr (MPIPE) {
         // rows 0..3 (stage-1 operands) and 8, 9 (twiddles) of the operand table, [6][64] 16-byte rows; rows 4..7 (stage 2,
         // which a transform needs last) come from L2, requested at the start of the phase (all ten in LDS would cost the
         // structures with the longest strides their third workgroup per CU)
@@ -1336,12 +1369,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // later the received block)
         auto row = [&](int u) -> v2f * {
             if constexpr (FIRQ)
-                return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
+                return reinterpret_cast<v2f *>(Hp + (u < SPW / 2 ? 0 : plen) + PRE + s0 * B) + (u % (SPW / 2)) * B;
             else
                 return fbw + u * B;
         };
         mdft_early dce;
-        if constexpr (MPIPE) dce = mdft_request();
+        if constexpr (MDFT || MD8) dce = mdft_request();
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
             if (lane < SPW * bps) {
@@ -1359,7 +1392,112 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         (void)xw;
         f4 xr[4], xi[4];                   // matrix-pipe transforms: DFT(swap X) = swap(N x[t]): xr = imaginary, xi = real parts
         (void)xr; (void)xi;
-        if constexpr (MD8) {
+        if constexpr (MDS) {
+            // Set t = SCS group + part.  IN: lane (m = lane % 16, g = lane / 16), element j = subcarrier SC (g + 4 j) + c of symbol
+            // 4 group + m / 4, c = 4 part + m % 4.  OUT: lane (ka = lane % 16, g'), element e = subcarrier ka + 16 kc of symbol
+            // 4 group + g', kc = e (SC = 4) or 2 e + part (SC = 8).
+            const int lm = lane & 15, lg = lane >> 4;
+            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + lane;
+            const h8 brh = __builtin_bit_cast(h8, dg[0]), brl = __builtin_bit_cast(h8, dg[64]);
+            const h8 bih = __builtin_bit_cast(h8, dg[128]), bil = __builtin_bit_cast(h8, dg[192]);
+            f4 twr[SCS], twi[SCS];
+#pragma unroll
+            for (int pp = 0; pp < SCS; ++pp) {
+                twr[pp] = __builtin_bit_cast(f4, dg[(8 + 2 * pp) * 64]);
+                twi[pp] = __builtin_bit_cast(f4, dg[(9 + 2 * pp) * 64]);
+            }
+            uint32_t li[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
+                const uint32_t *bw = reinterpret_cast<const uint32_t *>(row(sr));
+                li[t] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = SC * (lg + 4 * j) + c;
+                    uint32_t Lb;
+                    if (INJECT) {
+                        Lb = p.labels[(inj * S + s0 + sr) * N + n] & lmask;
+                    } else {
+                        const uint32_t bit = (uint32_t)n * (uint32_t)ks;
+                        Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
+                    }
+                    li[t] |= Lb << (8 * j);
+                    xw[t][j] = qlw[Lb];
+                    if (DUMP) {
+                        const hpair hw = __builtin_bit_cast(hpair, xw[t][j]);
+                        if (p.dump.labels_tx) p.dump.labels_tx[(s0 + sr) * N + n] = (uint8_t)Lb;
+                        if (p.dump.X) p.dump.X[(s0 + sr) * N + n] = make_float2((float)hw.y * qscale, (float)hw.x * qscale);
+                    }
+                }
+            }
+            // the labels once through the wave's (still unused) rows into OUTPUT order for phase D: one byte per subcarrier
+            uint8_t *lbytes = reinterpret_cast<uint8_t *>(row(0));
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lbytes[sr * N + SC * (lg + 4 * j) + c] = (uint8_t)(li[t] >> (8 * j));
+            }
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                labo[t] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kc = SC == 4 ? e : 2 * e + (t % SCS);
+                    labo[t] |= (uint32_t)lbytes[(4 * (t / SCS) + lg) * N + lm + 16 * kc] << (8 * e);
+                }
+                asm volatile("" : "+v"(labo[t]));
+            }
+            wave_sync();
+            STAMPF(9);
+            f4 tr[4], ti[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h8 xa = __builtin_bit_cast(h8, (u4){xw[t][0], xw[t][1], xw[t][2], xw[t][3]});
+                mma22(tr[t], ti[t], xa, brl, brh, bil, bih);
+                mdft_twiddle(tr[t], ti[t], twr[t % SCS], twi[t % SCS]);
+            }
+#pragma unroll
+            for (int gr = 0; gr < SGR; ++gr) {
+                if constexpr (SC == 4) radix4_elems(tr[gr], ti[gr]);
+                else radix8_elems(tr[2 * gr], ti[2 * gr], tr[2 * gr + 1], ti[2 * gr + 1]);
+            }
+            STAMPF(10);
+            // Tx write: element e of set t = sample ka + 16 kc of symbol s0 + 4 group + g' (the transform returned swap(N x): real parts
+            // in ti, imaginary parts in tr); sixteen lanes own one symbol, as in the quarter-wave layouts
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int s = s0 + 4 * (t / SCS) + lg;
+                uint32_t *hrow = Hp + PRE + s * B;
+                const bool lastsym = s == S - 1;
+                const int DtH = lastsym ? 0 : 2 * tail_off + s * TS - (PRE + (s + 1) * B);
+                const int DtL = lastsym ? 0 : DtH + S * TS - plen;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kc = SC == 4 ? e : 2 * e + (t % SCS);
+                    const int tl = lm + 16 * kc;
+                    const float re = ti[t][e], im = tr[t][e];
+                    auto put = [&](int i) {
+                        const float w = wtx[i];
+                        uint32_t hi, lo;
+                        split_h(mk(re * w, im * w), hi, lo);
+                        const int tlm = i >= B ? -1 : 0;                    // (DtH, DtL are zero for the last symbol)
+                        hrow[i + (DtH & tlm)] = hi;
+                        hrow[i + plen + (DtL & tlm)] = lo;
+                    };
+                    put(tl + mu);
+                    if (16 * kc + 15 >= N - mu) {
+                        if (tl >= N - mu) put(tl + mu - N);
+                    }
+                    if (16 * kc < rho) {
+                        if (tl < rho) put(tl + mu + N);
+                    }
+                }
+            }
+        } else if constexpr (MD8) {
             // labels and constellation words in INPUT element order: set c, element j = subcarrier N/16 (g + 4 j) + NC b + c;
             // the NC labels of one (j) sit in one staged word
             const int s = s0;
@@ -2073,13 +2211,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 hw[B] = lo;
             }
         } else {
-            const int s = s0 + lg;
-            if (s > 0 && ln < beta) {
-                const int idx = PRE + s * B + ln, it = (s - 1) * beta + ln;
-                uint32_t hi, lo;
-                split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
-                Hp[idx] = hi;
-                Lp[idx] = lo;
+#pragma unroll
+            for (int sb = 0; sb < SPW; sb += 4) {              // (sixteen lanes per symbol, four symbols at a time)
+                const int s = s0 + sb + lg;
+                if (s > 0 && ln < beta) {
+                    const int idx = PRE + s * B + ln, it = (s - 1) * beta + ln;
+                    uint32_t hi, lo;
+                    split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
+                    Hp[idx] = hi;
+                    Lp[idx] = lo;
+                }
             }
         }
         wave_sync();
@@ -2512,7 +2653,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
         auto row = [&](int u) -> v2f * {
             if constexpr (FIRQ)
-                return reinterpret_cast<v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B) + (u & 1) * B;
+                return reinterpret_cast<v2f *>(Hp + (u < SPW / 2 ? 0 : plen) + PRE + s0 * B) + (u % (SPW / 2)) * B;
             else
                 return fbw + u * B;
         };
@@ -2526,7 +2667,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         mdft_early dce;
-        if constexpr (MPIPE) dce = mdft_request();
+        if constexpr (MDFT || MD8) dce = mdft_request();
 #ifdef WOFDM_AUDIT
         aud_g = g; aud_ps = Ps; aud_pn = Pn;
 #endif
@@ -2536,7 +2677,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             const int jl = 8 * (lane & 15) + 2 * (lane >> 4), LW = SPW * B;
             const bool all_full = !DUMP && LW == 128 * NT;
             v2f *rxb = (FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B)) + jl;
-            const int dlt = FIR8 ? 0 : (plen - 4 * B) / 2;
+            const int dlt = FIR8 ? 0 : (plen - SPW * B) / 2;
             v2f *rxb1 = rxb + dlt;                                  // the lane's base in the plane-L chunk (samples from 2B on)
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
             // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
@@ -2550,7 +2691,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
-                v2f *dst = (FIR8 || jl < 2 * B - 128 * G ? rxb : rxb1) + 128 * G;
+                v2f *dst = (FIR8 || jl < (SPW / 2) * B - 128 * G ? rxb : rxb1) + 128 * G;
                 if (!FULLC) dst = valid ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
                 if (DUMP && p.dump.rx) {
@@ -2597,7 +2738,83 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // reference's Y times that ramp -- the tests put it back on the host; Xhat and everything behind it is the
         // reference's.)  Two passes: all main-tap loads in flight together, free of branches; the folded samples only
         // where there is an Rx tail at all.
-        if constexpr (MD8) {
+        if constexpr (MDS) {
+            (void)kap; (void)h2;
+            const int lm = lane & 15, lg = lane >> 4;
+            const u4 *dg = reinterpret_cast<const u4 *>(p.dftc) + lane;
+            const h8 brh = __builtin_bit_cast(h8, dg[0]), brl = __builtin_bit_cast(h8, dg[64]);
+            const h8 bih = __builtin_bit_cast(h8, dg[128]), bil = __builtin_bit_cast(h8, dg[192]);
+            f4 twr[SCS], twi[SCS];
+#pragma unroll
+            for (int pp = 0; pp < SCS; ++pp) {
+                twr[pp] = __builtin_bit_cast(f4, dg[(8 + 2 * pp) * 64]);
+                twi[pp] = __builtin_bit_cast(f4, dg[(9 + 2 * pp) * 64]);
+            }
+            h8 xh[4], xl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
+                const v2f *fy = row(sr) + gam;
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = SC * (lg + 4 * j) + c;
+                    v2f x = wmul(fy[n], wrx[n]);
+                    if (delta > 0) {
+                        if (n < delta) x = wfma(fy[n + N], wrx[n + N], x);
+                    }
+                    split_h(x, h[j], l[j]);
+                }
+                xh[t] = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
+                xl[t] = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+            }
+            wave_sync();
+            STAMPF(14);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                mma33(yr[t], yi[t], xl[t], brh, xh[t], brl, xh[t], brh, xl[t], bih, xh[t], bil, xh[t], bih);
+                mdft_twiddle(yr[t], yi[t], twr[t % SCS], twi[t % SCS]);
+            }
+#pragma unroll
+            for (int gr = 0; gr < SGR; ++gr) {
+                if constexpr (SC == 4) radix4_elems(yr[gr], yi[gr]);
+                else radix8_elems(yr[2 * gr], yi[2 * gr], yr[2 * gr + 1], yi[2 * gr + 1]);
+            }
+            STAMPF(15);
+            if (DUMP && p.dump.Y) {
+                const float us = p.dump_unscale_rx / p.rx_scale[sn * n_ch + ch];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kc = SC == 4 ? e : 2 * e + (t % SCS);
+                        p.dump.Y[(s0 + 4 * (t / SCS) + lg) * N + lm + 16 * kc] = make_float2(yr[t][e] * us, yi[t][e] * us);
+                    }
+            }
+            if (wv == 0) {
+                // pilot = symbol 0 = group 0 of lanes g' = 0: G = X0 / Y0, one 16-byte row of real and one of imaginary parts per part
+                f4 *G4 = reinterpret_cast<f4 *>(G);
+                if (lg == 0) {
+#pragma unroll
+                    for (int pp = 0; pp < SCS; ++pp) {
+                        f4 gr, gi;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const hpair hw = __builtin_bit_cast(hpair, qlw[(labo[pp] >> (8 * e)) & lmask]);
+                            const float x0r = (float)hw.y, x0i = (float)hw.x;
+                            const float y0r = yr[pp][e], y0i = yi[pp][e];
+                            const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
+                            gr[e] = (x0r * y0r + x0i * y0i) * inv;
+                            gi[e] = (x0i * y0r - x0r * y0i) * inv;
+                        }
+                        G4[pp * 16 + lm] = gr;
+                        G4[(SCS + pp) * 16 + lm] = gi;
+                    }
+                }
+                wave_sync();
+                if constexpr (RELAXF) post_flag(&flags[16], iter, lane);
+            }
+        } else if constexpr (MD8) {
             (void)kap; (void)h2;
             // Rx window / fold into INPUT element order (NC consecutive samples per element j), split, transform
             const int lb = lane & 15, lg = lane >> 4;
@@ -2854,6 +3071,38 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // ------------------------------------------------------------ D: equalise, demap, count
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         uint32_t be_f = 0, se_f = 0;                   // this frame's errors of the lane (SCALAR_ACC)
+        if constexpr (MDS) {
+            const int lm = lane & 15, lg = lane >> 4;
+            const f4 *G4 = reinterpret_cast<const f4 *>(G);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pp = t % SCS, s = s0 + 4 * (t / SCS) + lg;
+                const f4 gr = G4[pp * 16 + lm], gi = G4[(SCS + pp) * 16 + lm];
+                const f4 ehr = yr[t] * gr - yi[t] * gi, ehi = yr[t] * gi + yi[t] * gr;
+                const f4 lvi = ehr * 0.5f + 0.5f * (float)m1, lvq = ehi * -0.5f + 0.5f * (float)m1;
+                uint32_t iw = 0, qw = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    iw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lvi[e], (float)m1), e, iw);
+                    qw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lvq[e], (float)m1), e, qw);
+                    if (DUMP && p.dump.Xhat && s > 0)
+                        p.dump.Xhat[(s - 1) * N + lm + 16 * (SC == 4 ? e : 2 * e + pp)] = make_float2(ehr[e] * qscale, ehi[e] * qscale);
+                }
+                constexpr uint32_t GM = K == 2 ? 0u : (K == 4 ? 0x05050505u : 0x1B1B1B1Bu);
+                constexpr uint32_t LM = lmask * 0x01010101u;
+                const uint32_t cw = (iw << half) | qw;
+                const uint32_t gw = cw ^ ((cw >> 1) & GM);
+                uint32_t diff = (gw ^ labo[t]) & LM;
+                if (s == 0) diff = 0;                               // the pilot symbol is not counted
+                bit_err += __popc(diff);
+                sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
+                if (DUMP && p.dump.labels_rx && s > 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        p.dump.labels_rx[(s - 1) * N + lm + 16 * (SC == 4 ? e : 2 * e + pp)] = (uint8_t)((gw >> (8 * e)) & lmask);
+                }
+            }
+        }
         if constexpr (MD8) {
             if (s0 > 0) {
                 const f4 *G4 = reinterpret_cast<const f4 *>(G);
@@ -2892,7 +3141,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             g4i = reinterpret_cast<const f4 *>(G)[64 + lane];
         }
 #pragma unroll
-        for (int u = 0; u < (MD8 ? 0 : VS); ++u) {
+        for (int u = 0; u < ((MD8 || MDS) ? 0 : VS); ++u) {
             const int s = sym_of(u);
             if (s > 0) {
 #pragma unroll
@@ -3279,6 +3528,10 @@ template <int N, int K, int SPW> wofdm_kernel_fn pick_var(int mode, int var)
 template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
 {
     if (spw == 1) return pick_var<N, K, 1>(mode, var);
+    if constexpr (N == 64 || N == 128) {
+        if (spw == 13 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 13, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 14 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 14, WOFDM_VAR_PLAIN>(mode);
+    }
     if (spw == 9) {
         if constexpr (N <= WOFDM_TXMASK_MAX_N) {
             if (var == WOFDM_VAR_TXMASK) return pick_mode<N, K, 9, WOFDM_VAR_TXMASK>(mode);
