@@ -158,7 +158,12 @@ def test_tx_mask_one_frame_stage_by_stage(channels, system, n_fft, cp, k, inject
         plan.set_tx_mask(mask)
         fft_form = n_fft <= 256 and 3 * st.sym_len - 2 <= 1024 and not direct
         # fast-convolution form: 1024 twiddles + 8 scratch rows of 1024 points behind the frame
-        assert (info["lds_bytes"] >= 9 * 1024 * 8) == fft_form or n_fft == 512
+        if plan.kernel_id()[0] == 15:
+            # (N = 256 with the FIR on the matrix pipe: the mask's transforms run there too, without exchange scratch; the
+            # LDS behind the frame holds their tables and one spill row per wave instead)
+            assert fft_form and info["lds_bytes"] < 9 * 1024 * 8 + 51136
+        else:
+            assert (info["lds_bytes"] >= 9 * 1024 * 8) == fft_form or n_fft == 512
         gc, gd = plan.dump_frame(cell, frame, *((lab, noise.astype(np.complex64)) if inject else ()))
     assert np.array_equal(gd["labels_tx"], lab)
     assert int(gc[1]) == int(oc[1]) and int(gc[3]) == int(oc[3])

@@ -583,7 +583,9 @@ def _geometry_for(n_fft, layout, var):
         if var >= 2:
             env["fir_valu"] = 1                                                   # (else the masked variants run layout 9)
         return ("wtx", 32 if n_fft == 256 else 16, 16 if var >= 2 else 9, env)   # a mask forces one symbol per wave
-    if layout == 9:                                                               # Tx mask + matrix-pipe FIR: strides 4 | B, B >= N
+    if layout in (9, 15):                                                         # Tx mask + matrix-pipe FIR: strides 4 | B, B >= N
+        if layout == 9 and n_fft == 256 and var == 3:
+            env["dft_valu"] = 1                                                   # (else the fast-convolution mask runs layout 15)
         return ("wtx" if n_fft >= 256 else "WOLA"), 32 if n_fft >= 256 else 16, 16, env
     if layout == 2:
         env.update(fir_valu=1, max_spw=2)

@@ -48,3 +48,15 @@ with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
         print(rep, plan.run(off, F)[..., 0].ravel())
     for f in range(3):
         print("frame", f, plan.run(off + f, 1)[..., 0].ravel(), "oracle", O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128), snrs.astype(np.float64), seed, off + f, 1)[..., 0].ravel())
+if os.environ.get("MASK_DEBUG_TX") == "1":
+    # the instrumented kernel's on-air frame against the oracle's, symbol by symbol (real and imaginary parts apart)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        plan.set_allocation(active); plan.set_tx_mask(mask)
+        gc, gd = plan.dump_frame(cell, frame)
+        d = gd["tx"] - od["tx"]; sc = np.abs(od["tx"]).max()
+        Bst = st.stride
+        for sy in range(S):
+            seg = d[sy * Bst:(sy + 1) * Bst]
+            print("symbol %2d: max |re err| %.2e  max |im err| %.2e   first bad %s" % (sy, np.abs(seg.real).max() / sc, np.abs(seg.imag).max() / sc,
+                  np.where(np.abs(seg) > 1e-4 * sc)[0][:6]))
+        print("tail:", np.abs(d[S * Bst:]).max() / sc)

@@ -22,7 +22,14 @@ st = W.make_structure("wtx" if n <= 256 else "WOLA", n, 32)
 snr = np.arange(-5.0, 51.0, 5.0).astype(np.float32)
 cfg = W.make_cfg(st, k, 16, 21, 1, 12, 1, seed=2)
 frames = 62500 * 256 // n
+MASK = os.environ.get("STAMP_MASK") == "1"       # row f1: half-band allocation + Tx mask (build with -DWOFDM_STAMP_MASK)
+if MASK:
+    frames //= 4
 with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:1].astype(np.complex64), snr) as plan:
+    if MASK:
+        from wofdm_amd import channel_mask as CM
+        plan.set_allocation(CM.half_band_allocation(n))
+        plan.set_tx_mask(CM.tx_mask(st.sym_len))
     info = plan.info()
     grid, waves = info["workgroups"], info["waves_per_workgroup"]
     buf = torch.zeros(4 * 12 + grid * 16 * 16, dtype=torch.int64, device="cuda")
@@ -33,7 +40,12 @@ names = ["A4 Tx write (+ mask)", "wait barrier 1", "B3 trailing tile, power sums
          "C4 pilot estimate", "wait barrier 3", "D equalise/demap", "loop control",
          "A1 Philox data bits", "A2 labels, QAM", "A3 IFFT", "B1 overlap-add, operands", "B2 tiles: FIR + noise",
          "C1 gain, r = c + g n", "C2 Rx window loads", "C3 FFT"]
-order = [7, 8, 9, 10, 0, 1, 11, 12, 2, 3, 13, 14, 15, 4, 5, 6]
+if MASK:
+    names[0] = "A7 mask: write-back, hand-over, spill"
+    names[4] = "C  (whole phase)"
+    names[13:16] = ["A4 Tx write", "A5 mask: load, forward transform", "A6 mask: spectrum, inverse transform"]
+    print("kernel", info.get("kernel_id"), "LDS", info["lds_bytes"])
+order = [7, 8, 9, 10, 13, 14, 15, 0, 1, 11, 12, 2, 3, 4, 5, 6] if MASK else [7, 8, 9, 10, 0, 1, 11, 12, 2, 3, 13, 14, 15, 4, 5, 6]
 tot = st_.sum(axis=2)
 print("N=%d k=%d: %.2f ms, %d workgroups x %d waves; mean cycles per wave %.3e" % (n, k, ms, grid, waves, tot.mean()))
 for i in order:

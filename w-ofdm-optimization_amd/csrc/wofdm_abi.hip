@@ -102,6 +102,7 @@ struct wofdm_plan {
     uint32_t *d_amask = nullptr;       // [N/4] words, byte r bit 7: subcarrier j + r N/4 not loaded
     float2 *d_tmask = nullptr;         // [2P-1] circular impulse response of the Tx mask
     float2 *d_tspec = nullptr;         // [WOFDM_TXFFT_LEN] its fast-convolution spectrum (FFT form)
+    float *d_tspec4 = nullptr;         // the same x 2^4 in layout 15's order: [kc][re | im][lane][j] <-> bin lane + 64 j + 256 kc
     unsigned *d_status = nullptr;      // kernel status word (wofdm_kparams::status)
     uint4 *d_fira = nullptr;           // [n_ch][4][64] Toeplitz operands of the matrix-pipe FIR (MFMA A layout)
     float firm_sx = 1.f, firm_sh = 1.f; // powers of two carried by the f16 samples / f16 taps there
@@ -117,6 +118,13 @@ struct wofdm_plan {
 
 namespace {
 
+// words of the allocation table (wofdm_plan_set_allocation: N/4 in the plain order, then the layouts' own orders)
+size_t wofdm_amask_words(int N)
+{
+    const size_t NQ = (size_t)N / 4;
+    return N == 256 ? 2 * NQ + 256 : NQ + (NQ > 256 ? NQ : 256);
+}
+
 // Select the kernel variant from the plan's options and size everything that depends on it
 // (symbols per wave, LDS bytes, frame buffer length, occupancy).  Plan state changes only on success.
 int configure(wofdm_plan *pl)
@@ -131,11 +139,13 @@ int configure(wofdm_plan *pl)
     // (layouts 13 / 14 -- N = 64, 128 with the transforms on the matrix pipe -- are built without the allocation variant)
     const bool mdft = !pl->dft_valu && !(var == WOFDM_VAR_ALLOC && g.N <= 128);
     int spw = masked ? wofdm_spw_masked(g.N, g.B, firm) : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
+    // (layout 15: the fast-convolution mask at N = 256 with all four transforms on the matrix pipe)
+    if (var == WOFDM_VAR_TXFFT && g.N == 256 && spw == 9 && mdft && WOFDM_TXFFT_LEN == 1024) spw = 15;
     if (pl->max_spw > 0 && wofdm_nsym(spw, g.N) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
-                         + (var == WOFDM_VAR_TXFFT ? wofdm_txfft_lds_bytes() : 0u);
+                         + (var == WOFDM_VAR_TXFFT && spw != 15 ? wofdm_txfft_lds_bytes() : 0u);
     if (lds > 160u * 1024u)
         return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)", lds);
     wofdm_kernel_fn fn[4];
@@ -188,7 +198,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     kp.items_q = total_items / grid;
     kp.items_r = total_items % grid;
     kp.lds_bytes = pl->base.lds_bytes;
-    float2 *tm = pl->var == WOFDM_VAR_TXFFT ? pl->d_tspec : pl->d_tmask;
+    float2 *tm = pl->var == WOFDM_VAR_TXFFT ? (pl->spw == 15 ? reinterpret_cast<float2 *>(pl->d_tspec4) : pl->d_tspec) : pl->d_tmask;
     kp.tx_scale = pl->base.tx_scale;
     kp.dump_unscale_tx = pl->base.dump_unscale_tx;
     kp.dump_unscale_rx = pl->base.dump_unscale_rx;
@@ -330,8 +340,10 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     //   rows 4..7  stage 2, A operand: row a <-> k2 = a / 4 + 4 (a % 4), K slot (g, j) <-> n2 = 4 g + j
     //   rows 8, 9  the inter-stage twiddles exp(-2 pi i (4 g + j) a / 256), j < 4: real parts, imaginary parts (fp32)
     //   rows 10.. (N = 512, 1024: layout 12) the twiddles in front of the last, radix-N/256 stage, exp(-2 pi i c (lane + 64 j) / N),
-    //             c = 1 .. N/256 - 1: real parts, imaginary parts
-    const int dft_nc = g.N >= 512 ? g.N / 256 : (g.N == 128 ? 2 : 1);   // (rows beyond the first ten: N >= 512, and N = 128)
+    //             c = 1 .. N/256 - 1: real parts, imaginary parts  (N = 256: the same for 1024 points, the Tx mask of layout 15)
+    // (rows beyond the first ten: N >= 512, N = 128, and N = 256 for the 1024-point transforms of the Tx mask -- layout 15)
+    const int dft_nc = g.N >= 512 ? g.N / 256 : (g.N == 128 ? 2 : (g.N == 256 ? 4 : 1));
+    const int dft_n2 = g.N == 256 ? 1024 : g.N;
     std::vector<uint32_t> dftc((size_t)(10 + 2 * (dft_nc - 1)) * 64 * 4);
     {
         const double PI = 3.14159265358979323846;
@@ -374,8 +386,8 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
                     std::memcpy(&dftc[((size_t)10 * 64 + lane) * 4 + j], &t3r, 4);
                     std::memcpy(&dftc[((size_t)11 * 64 + lane) * 4 + j], &t3i, 4);
                 }
-                for (int c = 1; g.N >= 512 && c < dft_nc; ++c) {
-                    const double a2 = -2.0 * PI * (double)((c * (lane + 64 * j)) % g.N) / (double)g.N;
+                for (int c = 1; g.N >= 256 && c < dft_nc; ++c) {
+                    const double a2 = -2.0 * PI * (double)((c * (lane + 64 * j)) % dft_n2) / (double)dft_n2;
                     const float t2r = (float)std::cos(a2), t2i = (float)std::sin(a2);
                     std::memcpy(&dftc[((size_t)(10 + 2 * (c - 1)) * 64 + lane) * 4 + j], &t2r, 4);
                     std::memcpy(&dftc[((size_t)(11 + 2 * (c - 1)) * 64 + lane) * 4 + j], &t2i, 4);
@@ -475,6 +487,7 @@ int wofdm_plan_destroy(wofdm_plan *pl)
     if (pl->d_amask) (void)hipFree(pl->d_amask);
     if (pl->d_tmask) (void)hipFree(pl->d_tmask);
     if (pl->d_tspec) (void)hipFree(pl->d_tspec);
+    if (pl->d_tspec4) (void)hipFree(pl->d_tspec4);
     if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->d_fira) (void)hipFree(pl->d_fira);
     if (pl->d_dftc) (void)hipFree(pl->d_dftc);
@@ -491,14 +504,14 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
     HIP_TRY(hipSetDevice(pl->device));
     HIP_TRY(hipDeviceSynchronize());           // no launch of this plan may still read the mask
     const int N = pl->g.N, NQ = N / 4;
-    const size_t amask_words = (size_t)NQ + (size_t)(NQ > 256 ? NQ : 256);
+    const size_t amask_words = wofdm_amask_words(N);
     int nact = N;
     if (active) {
         nact = 0;
         // [0, NQ): word j, byte r <-> subcarrier j + r NQ; [NQ, 2 NQ): the quarter-wave order of
         // the N = 256 kernels, word 16 q + l, byte r <-> subcarrier l + 16 (q + 4 r)
         // N >= 512, [NQ, NQ + 256): the input element order of layout 12, word lane + 64 j, byte c <-> subcarrier
-        // N/16 (lane / 16 + 4 j) + NC (lane % 16) + c, NC = N / 256
+        // N/16 (lane / 16 + 4 j) + NC (lane % 16) + c, NC = N / 256; N = 256: the same with NC = 1 (layout 15) in [2 NQ, 2 NQ + 256)
         std::vector<uint32_t> words(amask_words, 0u);
         for (int n = 0; n < N; ++n) {
             if (active[n]) { ++nact; continue; }
@@ -507,10 +520,11 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
                 const int l = n & 15, t = n >> 4;
                 words[(size_t)(NQ + 16 * (t & 3) + l)] |= 0x80u << (8 * (t >> 2));
             }
-            if (N >= 512) {
-                const int nc = N / 256, a = n / (N / 16), r = n % (N / 16), b = r / nc, c = r % nc;   // n = N/16 a + NC b + c
+            if (N >= 512 || N == 256) {
+                // (N = 256, layout 15: one set, behind the quarter-wave part)
+                const int nc = N >= 512 ? N / 256 : 1, a = n / (N / 16), r = n % (N / 16), b = r / nc, c = r % nc;   // n = N/16 a + NC b + c
                 const int lane = 16 * (a & 3) + b, j = a >> 2;                                         // a = g + 4 j
-                words[(size_t)(NQ + lane + 64 * j)] |= 0x80u << (8 * c);
+                words[(size_t)((N == 256 ? 2 * NQ : NQ) + lane + 64 * j)] |= 0x80u << (8 * c);
             }
         }
         if (nact == 0) return fail(WOFDM_E_INVALID, "allocation loads no subcarrier");
@@ -534,7 +548,7 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
     }
     // impulse response of the mask: g = IDFT_{2P-1}(mask), in double on the host (complex in
     // general: main_channel_mask.m's centred raised cosine is not even around bin 0 when P is odd)
-    const int Lm = 2 * pl->g.P - 1, NQ = pl->g.N / 4;
+    const int Lm = 2 * pl->g.P - 1;
     std::vector<float2> gtd((size_t)Lm);
     for (int n = 0; n < Lm; ++n) {
         double re = 0.0, im = 0.0;
@@ -579,9 +593,21 @@ int wofdm_plan_set_tx_mask(wofdm_plan *pl, const float *mask)
         }
         if (!pl->d_tspec) HIP_TRY(hipMalloc(&pl->d_tspec, (size_t)MF * sizeof(float2)));
         HIP_TRY(hipMemcpy(pl->d_tspec, spec.data(), (size_t)MF * sizeof(float2), hipMemcpyHostToDevice));
+        if (MF == 1024) {
+            std::vector<float> spec4((size_t)2 * MF);
+            for (int kc = 0; kc < 4; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const float2 v = spec[(size_t)(lane + 64 * j + 256 * kc)];
+                        spec4[((size_t)(2 * kc + 0) * 64 + lane) * 4 + j] = 16.0f * v.x;
+                        spec4[((size_t)(2 * kc + 1) * 64 + lane) * 4 + j] = 16.0f * v.y;
+                    }
+            if (!pl->d_tspec4) HIP_TRY(hipMalloc(&pl->d_tspec4, spec4.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(pl->d_tspec4, spec4.data(), spec4.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (!pl->d_amask) {        // the mask kernels always read an allocation word
-        const size_t amask_words = (size_t)NQ + (size_t)(NQ > 256 ? NQ : 256);
+        const size_t amask_words = wofdm_amask_words(pl->g.N);
         HIP_TRY(hipMalloc(&pl->d_amask, amask_words * sizeof(uint32_t)));
         HIP_TRY(hipMemset(pl->d_amask, 0, amask_words * sizeof(uint32_t)));
     }

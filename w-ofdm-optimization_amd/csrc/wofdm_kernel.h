@@ -106,8 +106,10 @@ static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11 || spw
 static inline bool wofdm_is_small(int spw) { return spw == 13 || spw == 14; }
 // 9 = one symbol per wave, FIR on the matrix pipe, for the Tx-mask variants (any N <= 512): layout 8's frame format; the mask
 // stage works on the rows as fp32, phase B turns them into the f16 planes in place
-static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw == 12; }
-static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12; }
+// 15 = 9 at N = 256 for the fast-convolution Tx mask with every transform on the matrix pipe: the symbol's own two as in layout 12
+// (one set), the mask's two 1024-point ones as four sets each with no exchange in between (no mask scratch in LDS)
+static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw == 12 || spw == 15; }
+static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12 || spw == 15; }
 static inline int wofdm_firm_tiles(int spw) { return spw == 14 ? 11 : ((spw == 7 || spw == 11 || spw == 13) ? 10 : 9); }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
@@ -177,7 +179,9 @@ static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
     const int fixed = (N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
-    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta);
+    // (layout 15, behind the fall tails: 16 bytes of alignment, a row of 344 samples per wave for the mask stage's spill, and 64 spare
+    // bytes at the very end -- the target of the mask stage's stores that have no output)
+    return (unsigned)(fixed + 8 * wofdm_fbuf_len(N, T, spw, S, B) + 8 * S * beta + (spw == 15 ? 16 + S * 344 * 8 + 64 : 0));
 }
 
 // kernel registry (wofdm_kernel.hip)

@@ -82,10 +82,23 @@ namespace {
         __builtin_amdgcn_sched_barrier(0);                                                     \
     } while (0)
 #define STAMPF(slot) STAMP(slot)          /* finer marks inside the phases (slots 8..15) */
+#ifdef WOFDM_STAMP_MASK                   /* the Tx mask stage split into slots 13..15 instead of phase C */
+#define STAMPC(slot) do { } while (0)
+#define STAMPM(slot) STAMP(slot)
+#else
+#define STAMPC(slot) STAMP(slot)
+#define STAMPM(slot) do { } while (0)
+#endif
 #else
 // (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
 #define STAMPF(slot) do { } while (0)
+#define STAMPC(slot) do { } while (0)
+#ifdef WOFDM_MMARK
+#define STAMPM(slot) asm volatile("; wofdm_mmark " #slot)
+#else
+#define STAMPM(slot) do { } while (0)
+#endif
 #endif
 
 // The FIR's six MFMAs of a tile (fir_mma) are ONE asm block that starts on a 64-byte boundary: its 60 bytes sit in one
@@ -698,7 +711,9 @@ __device__ __forceinline__ void mdft_big(const h8 (&xh)[NC], const h8 (&xl)[NC],
         mma33(dr[s], di[s], c.arh, tl, c.arl, th, c.arh, th, c.aih, tl, c.ail, th, c.aih, th);
         if (s > 0) mdft_twiddle(dr[s], di[s], t2r[s], t2i[s]);
     }
-    if constexpr (NC == 2) {
+    if constexpr (NC == 1) {
+        yr[0] = dr[0]; yi[0] = di[0];
+    } else if constexpr (NC == 2) {
         yr[0] = dr[0] + dr[1]; yi[0] = di[0] + di[1];
         yr[1] = dr[0] - dr[1]; yi[1] = di[0] - di[1];
     } else {
@@ -709,6 +724,38 @@ __device__ __forceinline__ void mdft_big(const h8 (&xh)[NC], const h8 (&xl)[NC],
         yr[2] = a0r - a2r; yi[2] = a0i - a2i;
         yr[1] = a1r + a3i; yi[1] = a1i - a3r;                  // a1 - i a3
         yr[3] = a1r - a3i; yi[3] = a1i + a3r;                  // a1 + i a3
+    }
+}
+
+// The transposed flow of mdft_big<4> (decimation in frequency): the radix-4 stage over the sets FIRST -- input: set kc, element j =
+// element lane + 64 j + 256 kc, the OUTPUT order of mdft_big<4> --, then the twiddle om_1024^(c (lane + 64 j)) and per c the two matrix
+// stages: z[c + 4 n'] = sum_k om_256^(k n') [ om_1024^(k c) sum_kc (-i)^(kc c) Z[k + 256 kc] ].  Output: set c, element j = element
+// 4 (lane + 64 j) + c, the INPUT order of mdft_big<4>: a transform and its inverse back to back need no exchange (layout 15).
+__device__ __forceinline__ void mdft_big_dif4(const f4 (&zr)[4], const f4 (&zi)[4], const mdft_consts &c, const f4 (&t2r)[4],
+                                              const f4 (&t2i)[4], f4 (&yr)[4], f4 (&yi)[4])
+{
+    f4 ur[4], ui[4], tr[4], ti[4];
+    {
+        const f4 a0r = zr[0] + zr[2], a0i = zi[0] + zi[2], a1r = zr[0] - zr[2], a1i = zi[0] - zi[2];
+        const f4 a2r = zr[1] + zr[3], a2i = zi[1] + zi[3], a3r = zr[1] - zr[3], a3i = zi[1] - zi[3];
+        ur[0] = a0r + a2r; ui[0] = a0i + a2i;
+        ur[2] = a0r - a2r; ui[2] = a0i - a2i;
+        ur[1] = a1r + a3i; ui[1] = a1i - a3r;                  // a1 - i a3
+        ur[3] = a1r - a3i; ui[3] = a1i + a3r;                  // a1 + i a3
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s > 0) mdft_twiddle(ur[s], ui[s], t2r[s], t2i[s]);
+        h8 uh, ul;
+        mdft_split4(ur[s], ui[s], uh, ul);
+        mma33(tr[s], ti[s], ul, c.brh, uh, c.brl, uh, c.brh, ul, c.bih, uh, c.bil, uh, c.bih);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        mdft_twiddle(tr[s], ti[s], c.twr, c.twi);
+        h8 th, tl;
+        mdft_split4(tr[s], ti[s], th, tl);
+        mma33(yr[s], yi[s], c.arh, tl, c.arl, th, c.arh, th, c.aih, tl, c.ail, th, c.aih, th);
     }
 }
 
@@ -971,7 +1018,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 14 ? 22 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 20 : 18))
+    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12 || LAY == 15) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 14 ? 22 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 20 : 18))
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -992,8 +1039,8 @@ __device__ __forceinline__ void fir_lane(const v2f *w, const v2f *__restrict__ t
 // (main_channel_mask.m:387-390, 367-371); 2 = allocation + the per-symbol spectral Tx mask
 // dft_rc_filt (main_channel_mask.m:398-417), g_tmask = its length-(2P-1) circular impulse response
 template <int N, int K, int LAY, bool INJECT, bool DUMP, int VAR>
-__global__ void __launch_bounds__((LAY == 8 || LAY == 9 || LAY == 12) ? 1024 : ((LAY == 13 || LAY == 14) ? N : (LAY >= 4 ? 256 : 1024 / LAY)),
-                                   (LAY >= 4 && LAY != 8 && LAY != 9 && LAY != 12) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__((LAY == 8 || LAY == 9 || LAY == 12 || LAY == 15) ? 1024 : ((LAY == 13 || LAY == 14) ? N : (LAY >= 4 ? 256 : 1024 / LAY)),
+                                   (LAY >= 4 && LAY != 8 && LAY != 9 && LAY != 12 && LAY != 15) ? 3 : WOFDM_MIN_WAVES_PER_SIMD)
 wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const float *__restrict__ g_wrx, const float2 *__restrict__ g_h_,
                     const float *__restrict__ g_nlin, const int *__restrict__ gm,
@@ -1009,20 +1056,26 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // registers; mdft_big): lane (b = lane % 16, g = lane / 16) holds the INPUT elements N/16 (g + 4 j) + NC b + c and the
     // OUTPUT elements lane + 64 j + 256 c, j < 4, c < NC
     constexpr bool MD8 = LAY == 12;
+    // layout 15: the Tx mask's fast-convolution form at N = 256 with EVERYTHING on the matrix pipe: layout 9's frame handling (rows as fp32
+    // through the mask stage, f16 planes from phase B on), the symbol's own transforms as in layout 12 with NC = 1, and the mask's
+    // two 1024-point transforms as mdft_big<4> with one exchange between them
+    constexpr bool MDM = LAY == 15;
+    constexpr bool MDX = MD8 || MDM;                       // one symbol per wave, transforms by mdft_big
     // layouts 13, 14: N = 64 / 128, sixteen / eight symbols per wave, ONE matrix stage + the radix-N/16 stage in registers (radix4_elems)
     constexpr bool MDS = LAY == 13 || LAY == 14;
     constexpr int SC = N / 16, SCS = MDS ? SC / 4 : 1, SGR = 4 / SCS;      // elements per lane and symbol, sets per group, groups
-    constexpr bool MPIPE = MDFT || MD8 || MDS;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
-    constexpr int NC = MD8 ? N / 256 : 1;
+    constexpr bool MPIPE = MDFT || MD8 || MDS || MDM;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
+    constexpr int NC = MD8 ? N / 256 : 1;                  // (layout 15: one set)
     // layout 9: the Tx-mask variants with the FIR on the matrix pipe -- layout 8's frame format; the windowed symbols and the
     // mask stage live in the rows as fp32, phase B converts each row to the two f16 planes in place
-    constexpr bool FIR8M = LAY == 9;
+    constexpr bool FIR8M = LAY == 9 || LAY == 15;
     constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT || MDS, FIR8 = LAY == 8 || MD8 || FIR8M, FIRM = FIRQ || FIR8;
     constexpr int SPW = MDS ? 1024 / N : (FIR8 ? 1 : (LAY >= 5 ? 4 : LAY));     // symbols per wave
     constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 14 ? 11 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 10 : 9)), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
     static_assert(!FIR8 || FIR8M || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
     static_assert(!FIR8M || VAR >= 2, "layout 9 is the Tx-mask variants' matrix-pipe FIR layout");
+    static_assert(!MDM || (N == 256 && VAR == 3), "layout 15 is the fast-convolution Tx mask at N = 256");
     constexpr bool ALLOC = VAR >= 1, TXMASK = VAR == 2, TXFFT = VAR == 3;
     // flags instead of barriers 1 and 3 (not in the instrumented and masked variants, whose extra
     // stages have their own workgroup barriers)
@@ -1153,7 +1206,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // the frame buffer
     v2f *mtw = fbuf + gm[WOFDM_G_FBUF] + gm[WOFDM_G_S] * gm[WOFDM_G_BETA];
     v2f *mscr = mtw + maskfft_geo::MF;
-    if constexpr (TXFFT) fill_twiddles<maskfft_geo::MF>(mtw, tid, (int)blockDim.x);
+    if constexpr (TXFFT && !MDM) fill_twiddles<maskfft_geo::MF>(mtw, tid, (int)blockDim.x);
+    // Layout 15 keeps behind the fall tails instead (wofdm_lds_bytes) per wave a row of MDM_PK samples where the mask stage parks the
+    // part of its output that belongs to the NEXT symbol (the spill): that wave adds it when it turns its row into the f16 planes
+    // (phase B) -- no hand-over inside phase A.  (The mask's spectrum and the twiddles of its 1024-point transforms come from L2: an
+    // LDS copy gained under 1 %.)
+    constexpr int MDM_PK = 344;
+    v2f *mdm_park = reinterpret_cast<v2f *>(smem + ((L::off_fbuf + 8 * (gm[WOFDM_G_FBUF] + gm[WOFDM_G_S] * gm[WOFDM_G_BETA]) + 15) & ~15));
+    (void)mdm_park;
     __syncthreads();
     DELAY_AT(12);
 
@@ -1200,7 +1260,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // Error counters of the cell in progress: per-lane partial sums, or -- at N >= 512, where the
     // kernels are at their VGPR limit and per-lane accumulators ended up in scratch, re-read and
     // re-written every frame -- wave totals in scalar registers (one DPP reduction per frame).
-    constexpr bool SCALAR_ACC = N >= 512;
+    constexpr bool SCALAR_ACC = N >= 512 || LAY == 15;
     uint32_t bit_err = 0, sym_err = 0, nfr = 0;
     float nlin = 0.f;
 
@@ -1374,7 +1434,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 return fbw + u * B;
         };
         mdft_early dce;
-        if constexpr (MDFT || MD8) dce = mdft_request();
+        if constexpr (MDFT || MDX) dce = mdft_request();
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
             if (lane < SPW * bps) {
@@ -1497,7 +1557,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
-        } else if constexpr (MD8) {
+        } else if constexpr (MDX) {
             // labels and constellation words in INPUT element order: set c, element j = subcarrier N/16 (g + 4 j) + NC b + c;
             // the NC labels of one (j) sit in one staged word
             const int s = s0;
@@ -1517,7 +1577,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // byte c of the word: 0x80 when subcarrier n0 + c is NOT loaded (third part of the table: this layout's order);
                 // the flag rides in the label byte down to phase D
                 uint32_t am = 0;
-                if constexpr (ALLOC) am = g_amask[NQ + lane + 64 * j] & 0x80808080u;
+                if constexpr (ALLOC) am = g_amask[(MDM ? 2 * NQ : NQ) + lane + 64 * j] & 0x80808080u;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     uint32_t Lb;
@@ -1543,7 +1603,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             for (int j = 0; j < 4; ++j) {
                 const int n0 = (N / 16) * (lg + 4 * j) + NC * lb;
                 if constexpr (NC == 4) *reinterpret_cast<uint32_t *>(lbytes + n0) = labi[j];
-                else *reinterpret_cast<uint16_t *>(lbytes + n0) = (uint16_t)labi[j];
+                else if constexpr (NC == 2) *reinterpret_cast<uint16_t *>(lbytes + n0) = (uint16_t)labi[j];
+                else lbytes[n0] = (uint8_t)labi[j];
             }
             wave_sync();
 #pragma unroll
@@ -1566,6 +1627,135 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int c = 0; c < NC; ++c) { xr[c] = orr[c]; xi[c] = oi[c]; }
             STAMPF(10);
+            if constexpr (MDM) {
+            // ---- layout 15: the symbol goes into its fp32 row (layout 9's frame: tx_write below, element j = sample lane + 64 j;
+            // real parts in xi, imaginary parts in xr), the mask stage works on it there
+            const v2f *xt;
+            v2f *fb = fbw;
+            const bool last = s == S - 1;
+            {
+                const int Bs = last ? 0x3fffffff : B;
+                const int Dt = tail_off + s * TS - 4 - (s + 1) * B;
+                const bool body_tail = rho < gq[WOFDM_G_BETA];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = lane + 64 * j;
+                    const v2f x = mk(xi[0][j], xr[0][j]);
+                    auto put_plain = [&](int i) { fb[i] = wmul(x, wtx[i]); };
+                    auto put_tail = [&](int i) { fb[i + (i >= Bs ? Dt : 0)] = wmul(x, wtx[i]); };
+                    if (body_tail) put_tail(t + mu);
+                    else put_plain(t + mu);
+                    if (63 + 64 * j >= N - L::CPCS_MAX)
+                        if (t >= N - mu) put_plain(t + mu - N);
+                    if (64 * j < L::CPCS_MAX)
+                        if (t < rho) put_tail(t + mu + N);
+                }
+                xt = last ? fb + B : tailb + s * TS;
+            }
+            // dft_rc_filt as fast convolution (see the VALU form below: y = IDFT_MF(DFT_MF(x) . g_tmask), outputs at j = n + P - 1),
+            // both 1024-point transforms on the matrix pipe and NO exchange between them: the forward transform (mdft_big<4>)
+            // takes the symbol as element 4 (lane + 64 j) + c of set c and returns bin lane + 64 j + 256 kc in set kc; the
+            // inverse one runs the transposed flow (mdft_big_dif4) from that order back to the first.  The samples enter scaled
+            // by 2^-4 (so that the 16-term sums of stage 1 stay in the f16 range), which the spectrum table undoes; the inverse
+            // transform is swap(DFT(swap(.))): the spectrum product is written swapped, real parts come back in the second array.
+            const int P = gq[WOFDM_G_P];
+            wave_sync();
+            STAMPM(13);
+            f4 m2r[4], m2i[4];
+            {
+                const u4 *dl = reinterpret_cast<const u4 *>(p.dftc) + 10 * 64 + lane;      // (rows 10..15: L2)
+#pragma unroll
+                for (int c = 1; c < 4; ++c) {
+                    m2r[c] = __builtin_bit_cast(f4, dl[(2 * (c - 1)) * 64]);
+                    m2i[c] = __builtin_bit_cast(f4, dl[(2 * (c - 1) + 1) * 64]);
+                }
+                m2r[0] = m2i[0] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            // Which elements can fall where is known at compile time from N <= B <= P <= PMAX (this form of the mask runs when
+            // 3 P - 2 <= 1024): element K = 256 j + c of lane l is sample 4 l + K.  Everything below tests only what can fail, and
+            // instead of branching around a load or store sends the lanes it does not concern to a spare address (loads: the
+            // zero words in front of the frame; stores: eight bytes at the end of the workgroup's LDS) -- per-lane bases once,
+            // the element's K as the instruction's offset.
+            constexpr int PMAX = (N + L::CPCS_MAX) < (maskfft_geo::MF + 2) / 3 ? (N + L::CPCS_MAX) : (maskfft_geo::MF + 2) / 3;
+            const v2f *zeros = reinterpret_cast<const v2f *>(Hp);
+            v2f *spare = reinterpret_cast<v2f *>(smem + (p.lds_bytes - 8));
+            h8 mh[4], ml[4];
+            {
+                const v2f *pF = fb + 4 * lane, *pT = xt - B + 4 * lane;      // sample m = 4 l + K at pF[K] (row) or pT[K] (fall tail)
+                const int m0 = 4 * lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t wh[4], wl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int KE = 256 * j + c;
+                        wh[j] = 0u; wl[j] = 0u;
+                        if (KE < PMAX) {                                    // (else: zeros at compile time)
+                            const v2f *src = pF;
+                            if (KE + 252 >= N) src = (m0 < B - KE) ? pF : pT;            // m < B: always so in the first quarter
+                            if (KE + 252 >= N) src = (m0 < P - KE) ? src : zeros - KE;    // m < P
+                            split_h(wmul(src[KE], 0.0625f), wh[j], wl[j]);
+                        }
+                    }
+                    mh[c] = __builtin_bit_cast(h8, (u4){wh[0], wh[1], wh[2], wh[3]});
+                    ml[c] = __builtin_bit_cast(h8, (u4){wl[0], wl[1], wl[2], wl[3]});
+                }
+            }
+            f4 Fr[4], Fi[4];
+            mdft_big<4, false>(mh, ml, dc, m2r, m2i, Fr, Fi);
+            STAMPM(14);
+            f4 zr[4], zi[4];
+            {
+                // g_tmask here: the mask's spectrum as [kc][re | im][lane] rows of four (element j), times 2^4 (wofdm_abi.hip), from L2
+                const f4 *G4 = reinterpret_cast<const f4 *>(g_tmask) + lane;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const f4 gr = G4[(2 * kc) * 64], gi = G4[(2 * kc + 1) * 64];
+                    zr[kc] = Fr[kc] * gi + Fi[kc] * gr;
+                    zi[kc] = Fr[kc] * gr - Fi[kc] * gi;
+                }
+            }
+            f4 ymi[4], ymr[4];
+            mdft_big_dif4(zr, zi, dc, m2r, m2i, ymi, ymr);
+            STAMPM(15);
+            // own row <- y[0..P): element 4 l + K is output n = 4 l + K - (P - 1)
+            const int L4 = 4 * lane - (P - 1);
+            {
+                v2f *pF = fb + L4, *pT = last ? pF : tailb + s * TS - B + L4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int KE = 256 * j + c;
+                        if (KE + 252 >= N - 1 && KE <= 2 * PMAX - 2) {                       // (else: never an output of the row)
+                            v2f *dst = pF;
+                            if (KE + 252 - (N - 1) >= N) dst = (L4 < B - KE) ? pF : pT;      // n < B, else the fall tail
+                            if (KE < PMAX - 1) dst = (L4 >= -KE) ? dst : spare - KE;          // n >= 0
+                            if (KE + 252 >= 2 * N - 1) dst = (L4 < P - KE) ? dst : spare - KE;   // n < P
+                            dst[KE] = mk(ymr[c][j], ymi[c][j]);
+                        }
+                    }
+            }
+            // y[P..2P-1), which main_channel_mask.m adds to the first P - 1 samples of the NEXT symbol, is parked in the wave's own
+            // row behind the frame: the next wave (and, for the part that reaches into that symbol's fall tail, the one after it)
+            // adds it in phase B
+            if (!last) {
+                const int L5 = L4 - P;                                       // spill sample jx = 4 l + K + (L5 - 4 l)
+                v2f *qF = mdm_park + wv * MDM_PK + L5;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int KE = 256 * j + c;
+                        if (KE + 252 >= 2 * N - 1) {                                        // (else: never part of the spill)
+                            v2f *dst = qF;
+                            if (KE < 2 * PMAX - 1) dst = (L5 >= -KE) ? dst : spare - KE;      // jx >= 0
+                            if (KE + 252 >= 3 * N - 2) dst = (L5 < P - 1 - KE) ? dst : spare - KE;   // jx < P - 1
+                            dst[KE] = mk(ymr[c][j], ymi[c][j]);
+                        }
+                    }
+            }
+            } else {
             // Tx write: output element (kc, j) = sample t = lane + 64 (j + 4 kc); real parts in xi, imaginary parts in xr
             const bool lastsym = s == S - 1;
             uint32_t *hrow = Hp + 8 + 2 * B * s;
@@ -1628,6 +1818,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             };
             if (body_tail) tx12(std::true_type{});
             else tx12(std::false_type{});
+            }
         } else {
 #pragma unroll
         for (int u = 0; u < VS; ++u) {
@@ -1988,6 +2179,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             v2f *scr = mscr + wv * (MF / 2);          // every wave its own 4 KB exchange buffer
             v2f y[1][MBPL][4];
             wave_sync();
+            STAMPM(13);
 #pragma unroll
             for (int q = 0; q < MBPL; ++q)
 #pragma unroll
@@ -2001,12 +2193,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     y[0][q][r] = xm;
                 }
             fft_1024_half<-1>(y, scr, mtw, lane);
+            STAMPM(14);
 #pragma unroll
             for (int q = 0; q < MBPL; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     y[0][q][r] = cmul(y[0][q][r], ldg2(g_tmask + lane + 64 * q + r * MQ));
             fft_1024_half<+1>(y, scr, mtw, lane);
+            STAMPM(15);
             // own row <- y[0..P): element j = n + P - 1
 #pragma unroll
             for (int q = 0; q < MBPL; ++q)
@@ -2162,8 +2356,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // the same bytes -- becomes its two f16 planes in place; the last symbol's own fall tail, which sits behind its
             // row, becomes the virtual row the trailing tile reads.  One more hand-over: the successor's first tile reaches
             // back into this row's last samples (flags [48 + w], or a barrier in the instrumented kernels).
+            // (layout 15: the mask stage of the wave in front parked its spill -- P - 1 samples from this row's first on; the part
+            // beyond B reaches into THIS symbol's fall tail, which the next wave, or the virtual row, takes along)
             v2f *fb = reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0);
-            if (s0 > 0 && lane < beta) fb[lane] = fb[lane] + tailb[(s0 - 1) * beta + lane];
+            if (s0 > 0 && lane < beta) {
+                v2f t = tailb[(s0 - 1) * beta + lane];
+                if constexpr (MDM) {
+                    if (s0 > 1 && lane < beta - 1) t = t + mdm_park[(s0 - 2) * MDM_PK + B + lane];
+                }
+                fb[lane] = fb[lane] + t;
+            }
             wave_sync();
             constexpr int RQ = (N + L::CPCS_MAX + 63) / 64;
             v2f xs[RQ];
@@ -2172,9 +2374,25 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int i = lane + 64 * q;
                 xs[q] = i < B ? fb[i] : mk(0.f, 0.f);
             }
+            if constexpr (MDM) {
+                if (s0 > 0) {
+                    const int lim = min(B, gq[WOFDM_G_P] - 1);
+                    const v2f *pk = mdm_park + (s0 - 1) * MDM_PK, *zeros = reinterpret_cast<const v2f *>(Hp);
+#pragma unroll
+                    for (int q = 0; q < RQ; ++q) {
+                        const int i = lane + 64 * q;
+                        if (64 * q < MDM_PK) xs[q] = xs[q] + *((i < lim) ? pk + i : zeros);
+                    }
+                }
+            }
             const bool lastsym = s0 == S - 1;
             v2f xtl = mk(0.f, 0.f);
-            if (lastsym && lane < beta) xtl = fb[B + lane];
+            if (lastsym && lane < beta) {
+                xtl = fb[B + lane];
+                if constexpr (MDM) {
+                    if (s0 > 0 && lane < beta - 1) xtl = xtl + mdm_park[(s0 - 1) * MDM_PK + B + lane];
+                }
+            }
             wave_sync();
             uint32_t *hrow = Hp + 8 + 2 * B * s0;
 #pragma unroll
@@ -2667,7 +2885,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         const float g = __builtin_amdgcn_sqrtf(Ps * nlin * __builtin_amdgcn_rcpf(Pn));   // lengths cancel (m:289-292)
         mdft_early dce;
-        if constexpr (MDFT || MD8) dce = mdft_request();
+        if constexpr (MDFT || MDX) dce = mdft_request();
 #ifdef WOFDM_AUDIT
         aud_g = g; aud_ps = Ps; aud_pn = Pn;
 #endif
@@ -2725,7 +2943,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if (DUMP && p.dump.gain && tid == 0)
             p.dump.gain[0] = g * p.dump_unscale_rx * ((FIRM && !INJECT) ? 1.0f / WOFDM_NOISE_UNSCALE : 1.0f);
         wave_sync();
-        STAMPF(13);
+        STAMPC(13);
 
         // remove_redundancy, windowRx, overlap_and_add, circular_shift (m:302-308) collapse to
         // z[t] = sum_{m = t+kappa+delta/2 (mod N), m < N+delta} w_rx[m] y[gamma+m]
@@ -2769,7 +2987,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 xl[t] = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
             }
             wave_sync();
-            STAMPF(14);
+            STAMPC(14);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 mma33(yr[t], yi[t], xl[t], brh, xh[t], brl, xh[t], brh, xl[t], bih, xh[t], bil, xh[t], bih);
@@ -2780,7 +2998,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if constexpr (SC == 4) radix4_elems(yr[gr], yi[gr]);
                 else radix8_elems(yr[2 * gr], yi[2 * gr], yr[2 * gr + 1], yi[2 * gr + 1]);
             }
-            STAMPF(15);
+            STAMPC(15);
             if (DUMP && p.dump.Y) {
                 const float us = p.dump_unscale_rx / p.rx_scale[sn * n_ch + ch];
 #pragma unroll
@@ -2814,7 +3032,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 wave_sync();
                 if constexpr (RELAXF) post_flag(&flags[16], iter, lane);
             }
-        } else if constexpr (MD8) {
+        } else if constexpr (MDX) {
             (void)kap; (void)h2;
             // Rx window / fold into INPUT element order (NC consecutive samples per element j), split, transform
             const int lb = lane & 15, lg = lane >> 4;
@@ -2836,7 +3054,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
             }
             wave_sync();
-            STAMPF(14);
+            STAMPC(14);
             const mdft_consts dc = mdft_load(dce);
             f4 t2r[NC], t2i[NC];
             mdft_tw2(t2r, t2i);
@@ -2853,7 +3071,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             mdft_big<NC, false>(xh, xl, dc, t2r, t2i, orr, oi);
 #pragma unroll
             for (int c = 0; c < NC; ++c) { yr[c] = orr[c]; yi[c] = oi[c]; }
-            STAMPF(15);
+            STAMPC(15);
             if (DUMP && p.dump.Y) {
                 const float us = p.dump_unscale_rx / p.rx_scale[sn * n_ch + ch];
 #pragma unroll
@@ -2931,7 +3149,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         }
         wave_sync();
-        STAMPF(14);
+        STAMPC(14);
         if constexpr (MDFT) {
             const mdft_consts dc = mdft_load(dce);
             f4 tr[4], ti[4];
@@ -2953,7 +3171,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
         } else if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
         else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
-        STAMPF(15);
+        STAMPC(15);
 
         if constexpr (MDFT) {
             if (DUMP && p.dump.Y) {
@@ -3103,7 +3321,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
         }
-        if constexpr (MD8) {
+        if constexpr (MDX) {
             if (s0 > 0) {
                 const f4 *G4 = reinterpret_cast<const f4 *>(G);
 #pragma unroll
@@ -3141,7 +3359,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             g4i = reinterpret_cast<const f4 *>(G)[64 + lane];
         }
 #pragma unroll
-        for (int u = 0; u < ((MD8 || MDS) ? 0 : VS); ++u) {
+        for (int u = 0; u < ((MDX || MDS) ? 0 : VS); ++u) {
             const int s = sym_of(u);
             if (s > 0) {
 #pragma unroll
@@ -3551,6 +3769,7 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
             return var ? pick_mode<N, K, 8, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 8, WOFDM_VAR_PLAIN>(mode);
     }
     if constexpr (N == 256) {
+        if (spw == 15) return var == WOFDM_VAR_TXFFT ? pick_mode<N, K, 15, WOFDM_VAR_TXFFT>(mode) : nullptr;
         if ((spw == 10 || spw == 11) && var <= WOFDM_VAR_ALLOC) {
             if (spw == 10) return var ? pick_mode<N, K, 10, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 10, WOFDM_VAR_PLAIN>(mode);
             return var ? pick_mode<N, K, 11, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 11, WOFDM_VAR_PLAIN>(mode);
