@@ -92,11 +92,13 @@ namespace {
 #else
 // (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
-#define STAMPF(slot) do { } while (0)
-#define STAMPC(slot) do { } while (0)
-#ifdef WOFDM_MMARK
+#ifdef WOFDM_MMARK      /* developer builds (hipcc -S): the finer marks as comments too */
+#define STAMPF(slot) asm volatile("; wofdm_mmark " #slot)
+#define STAMPC(slot) asm volatile("; wofdm_mmark " #slot)
 #define STAMPM(slot) asm volatile("; wofdm_mmark " #slot)
 #else
+#define STAMPF(slot) do { } while (0)
+#define STAMPC(slot) do { } while (0)
 #define STAMPM(slot) do { } while (0)
 #endif
 #endif
