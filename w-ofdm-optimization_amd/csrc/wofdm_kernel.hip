@@ -629,7 +629,9 @@ __device__ __forceinline__ void fill_twiddles_qw(v2f *tw, int tid, int nthreads)
 // statement behind every chain: it takes the chain's results AND all its operands (so they stay allocated, and apart, up
 // to there) and spends the 12 wait states the hand-written chain has behind it.  tests/test_code_layout.py checks both
 // in the built library: no destination on an operand, no VALU write to an operand within 12 cycles of its MFMA.
+#ifndef WOFDM_MMA_TAIL
 #define WOFDM_MMA_TAIL "s_nop 7\n\ts_nop 3"
+#endif
 __device__ __forceinline__ void mma33(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1, h8 a2, h8 b2,
                                       h8 a3, h8 b3, h8 a4, h8 b4, h8 a5, h8 b5)
 {
