@@ -211,6 +211,35 @@ def test_tx_mask_sweep_and_removal(channels, S):
         assert (np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)) <= max(2, 1e-4 * bits)).all()
 
 
+@pytest.mark.parametrize("system,cp", [("wtx", 32), ("WOLA", 24), ("CP", 0)])
+def test_tx_mask_kernels_count_the_same(channels, system, cp):
+    """The three masked kernels of N = 256 -- every transform on the matrix pipe (layout 15), FIR on the matrix pipe and the
+    transforms on the VALU (layout 9, plan option dft_valu), everything on the VALU (layout 1, fir_valu) -- on the same frames:
+    the same decisions but for a handful of symbols on a boundary; repeated launches bit-identical."""
+    st = W.make_structure(system, 256, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.arange(0.0, 36.0, 6.0).astype(np.float32)
+    h = channels[3:5].astype(np.complex64)
+    cfg = W.make_cfg(st, 4, 16, 21, 2, snrs.size, 1, seed=21)
+    active, mask = CM.half_band_allocation(256), CM.tx_mask(st.sym_len).astype(np.float32)
+    got = {}
+    for layout, opts in ((15, {}), (9, {"dft_valu": 1}), (1, {"fir_valu": 1})):
+        with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+            for key, val in opts.items():
+                plan.set_option(key, val)
+            plan.set_allocation(active)
+            plan.set_tx_mask(mask)
+            assert plan.kernel_id() == (layout, 3)
+            a, b = plan.run(7, 400), plan.run(7, 400)
+            assert np.array_equal(a, b)
+            got[layout] = a
+    ref = got[1]
+    for layout in (15, 9):
+        assert np.array_equal(got[layout][..., 1], ref[..., 1]) and np.array_equal(got[layout][..., 3], ref[..., 3])
+        d = np.abs(got[layout][..., 0].astype(np.int64) - ref[..., 0].astype(np.int64))
+        assert d.max() <= 4 and d.sum() <= 12, (layout, d.ravel())
+
+
 def test_tx_mask_limits(channels):
     st = W.make_structure("WOLA", 1024, 32)
     cfg = W.make_cfg(st, 2, 16, 21, 1, 1, 1)
