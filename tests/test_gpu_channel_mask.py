@@ -240,6 +240,48 @@ def test_tx_mask_kernels_count_the_same(channels, system, cp):
         assert d.max() <= 4 and d.sum() <= 12, (layout, d.ravel())
 
 
+@pytest.mark.parametrize("system,n_fft,cp,k,opts", [("wtx", 256, 32, 4, {}), ("WOLA", 256, 24, 6, {}), ("wtx", 256, 32, 4, {"dft_valu": 1}),
+                                                     ("WOLA", 128, 16, 4, {})])
+def test_tx_mask_production_and_instrumented_kernels_count_the_same(channels, system, n_fft, cp, k, opts):
+    """The stage-by-stage parity of the masked variant runs the instrumented kernels; the same injected frames through the
+    PRODUCTION kernel of the same layout (15, 9) must give the same error counters."""
+    import torch
+    S, seed, F = 16, 23, 24
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    h = channels[30:31].astype(np.complex64)
+    snrs = np.array([8.0 + 3.0 * (k - 2), 18.0 + 3.0 * (k - 2)], np.float32)
+    active, mask = CM.half_band_allocation(n_fft), CM.tx_mask(st.sym_len).astype(np.float32)
+    cfg = W.make_cfg(st, k, S, 21, 1, 2, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True, active=active, tx_mask=mask.astype(np.float64))
+    nl = O.noise_len(osys)
+    labels = np.zeros((2, F, S, n_fft), np.uint8)
+    noise = np.zeros((2, F, nl), np.complex64)
+    for cell in range(2):
+        for f in range(F):
+            labels[cell, f] = O.gen_labels(osys, seed, cell, f)
+            noise[cell, f] = O.gen_noise(osys, seed, cell, f)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        for key, val in opts.items():
+            plan.set_option(key, val)
+        plan.set_allocation(active)
+        plan.set_tx_mask(mask)
+        assert plan.kernel_id() == ((15 if n_fft == 256 and not opts else 9), 3)
+        counts = plan.new_counts()
+        plan.launch_injected(F, torch.from_numpy(labels).cuda(), torch.from_numpy(noise.view(np.float32).reshape(2, F, nl, 2)).cuda(), counts)
+        torch.cuda.synchronize()
+        plan.status()
+        prod = counts.cpu().numpy().view(np.uint64).reshape(2, 4).astype(np.int64)
+        inst = np.zeros((2, 4), np.int64)
+        for cell in range(2):
+            for f in range(F):
+                gc, _ = plan.dump_frame(cell, f, labels[cell, f], noise[cell, f])
+                inst[cell] += gc.astype(np.int64)
+    assert np.array_equal(prod[:, 1], inst[:, 1]) and np.array_equal(prod[:, 3], inst[:, 3])
+    assert prod[:, 0].min() > 50, prod
+    assert np.abs(prod - inst).max() <= 2, (prod, inst)
+
+
 def test_tx_mask_limits(channels):
     st = W.make_structure("WOLA", 1024, 32)
     cfg = W.make_cfg(st, 2, 16, 21, 1, 1, 1)
