@@ -46,6 +46,7 @@ def scan(co):
     MFMAs, {function: number of flat_* instructions}, {function: number of v_pk_* instructions with op_sel:[..]})."""
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
     fn, run, out, flat, swz, pending = None, [], [], {}, {}, []
+    last_wr, last_ins = set(), ""          # vector registers the previous instruction wrote (a vector-ALU instruction only)
     rng = lambda t: (lambda m: range(int(m.group(1)), int(m.group(2)) + 1))(re.match(r"v\[(\d+):(\d+)\]", t))  # noqa: E731
     for line in dis.split("\n"):
         m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
@@ -80,6 +81,13 @@ def scan(co):
             if pend["cyc"] >= 12 or ins.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")):
                 pending.remove(pend)
         if "v_mfma" in line:
+            # the MFMA does not see what the vector instruction DIRECTLY in front of it wrote (tools/ubench/mfma_after_mix.hip: one
+            # instruction in between is enough); the compiler spaces its own instructions, not the inline-asm ones of split_h
+            srcs = set()
+            for t in re.findall(r"v\[\d+:\d+\]", ins)[1:]:
+                srcs |= set(rng(t))
+            if srcs & last_wr:
+                swz.setdefault("__raw__", []).append((fn[:70], last_ins[:60], ins[:60]))
             run.append(int(m.group(1), 16))
             ops0 = re.findall(r"v\[\d+:\d+\]", ins)
             if len(ops0) >= 3:
@@ -91,6 +99,12 @@ def scan(co):
             if len(run) > 1:
                 out.append((fn, run[0], run[-1] + 8, len(run)))
             run = []
+        last_wr, last_ins = set(), ins
+        if ins.startswith("v_") and not ins.startswith("v_mfma") and not ins.startswith(("v_cmp_", "v_cmpx_")) and " " in ins:
+            d = ins.split(None, 1)[1].split(",")[0].strip()
+            mm = re.match(r"v\[(\d+):(\d+)\]", d) or re.match(r"v(\d+)$", d)
+            if mm:
+                last_wr = set(range(int(mm.group(1)), int(mm.group(mm.lastindex)) + 1))
     return out, flat, swz
 
 
@@ -112,6 +126,8 @@ def test_mfma_chains_sit_in_one_line_and_no_kernel_uses_flat_instructions():
         for co in _code_objects(LIB, tmp):
             chains, flat, swz = scan(co)
             assert not swz.pop("__overlap__", []), "an MFMA's destination overlaps its own operand"
+            raw = swz.pop("__raw__", [])
+            assert not raw, ("a vector instruction writes an MFMA's source directly in front of it", raw[:5], len(raw))
             war = swz.pop("__war__", [])
             assert not war, ("an MFMA operand is overwritten within 12 cycles of the MFMA", war[:5])
             for fn, a, b, n in chains:

@@ -757,6 +757,23 @@ def test_mfma_trains_only_hit_op_sel_swizzles():
             print("\nop_sel-swizzled v_pk_add_f32 beside trains of three-blocks: %s wrong values" % row["bystanders_bad"])
 
 
+def test_mfma_sees_a_vector_write_one_instruction_earlier():
+    """What mma_operand_fence (wofdm_kernel.hip) and the distance check of tests/test_code_layout.py rest on, on THIS GPU
+    (tools/ubench/mfma_after_mix.hip --quick): an MFMA whose operand word was written by the vector instruction DIRECTLY in front of
+    it computes with the old word (printed, not asserted); with one or more instructions in between it never does."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "native", "mfma_after_mix")
+    assert os.path.exists(exe), "make -C tests/native"
+    r = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [dict(kv.split("=") for kv in l.split()[1:]) for l in r.stdout.split("\n") if l.startswith("RESULT")]
+    assert len(rows) == 8, r.stdout
+    for row in rows:
+        assert all(int(row[g]) == 0 for g in ("gap1", "gap2", "gap4", "gap8")), row
+    print("\nwrong MFMA results with the operand written directly in front: "
+          + ", ".join("%s of %s" % (row["gap0"], row["total"]) for row in rows))
+
+
 def test_lds_poison_tool_works():
     """The helper's own check: a fresh LDS allocation shows what the previous workgroup on the CU left there."""
     lib = _poison()

@@ -153,6 +153,14 @@ __device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(y.y));
     lo = l;
 }
+// A matrix operand built from split_h words must not reach its MFMA straight from the last v_fma_mixhi_f16: the MFMA does not see
+// what the vector instruction DIRECTLY in front of it wrote (tools/ubench/mfma_after_mix.hip: every such result wrong, one instruction
+// in between and none is).  The compiler keeps that distance for the instructions it knows -- the mix instructions above are inline
+// asm.  One wait state that both operand halves pass through; tests/test_code_layout.py checks the built library.
+__device__ __forceinline__ void mma_operand_fence(h8 &hi, h8 &lo)
+{
+    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));
+}
 __device__ __forceinline__ v2f join_h(uint32_t hi, uint32_t lo)
 {
     return __builtin_convertvector(__builtin_bit_cast(h2, hi), v2f)
@@ -691,6 +699,7 @@ __device__ __forceinline__ void mdft_split4(f4 re, f4 im, h8 &hi, h8 &lo)
     split_h(mk(re.w, im.w), h[3], l[3]);
     hi = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
     lo = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+    mma_operand_fence(hi, lo);
 }
 // N = 256 NC (layout 12): n = N/16 a + NC b + c, k = ka + 16 kb + 256 kc.  Per c the two stages above on the 256 elements
 // x[N/16 a + NC b + c] (stage 1 over a, twiddle om256^(b ka), stage 2 over b: the same operand and twiddle rows as N = 256),
@@ -1703,6 +1712,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                     mh[c] = __builtin_bit_cast(h8, (u4){wh[0], wh[1], wh[2], wh[3]});
                     ml[c] = __builtin_bit_cast(h8, (u4){wl[0], wl[1], wl[2], wl[3]});
+                    mma_operand_fence(mh[c], ml[c]);
                 }
             }
             f4 Fr[4], Fi[4];
@@ -2989,6 +2999,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
                 xh[t] = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
                 xl[t] = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                mma_operand_fence(xh[t], xl[t]);
             }
             wave_sync();
             STAMPC(14);
@@ -3070,6 +3081,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int j = 0; j < 4; ++j) split_h(vin[c][j], h[j], l[j]);
                 xh[c] = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
                 xl[c] = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                mma_operand_fence(xh[c], xl[c]);
             }
             f4 orr[NC], oi[NC];
             mdft_big<NC, false>(xh, xl, dc, t2r, t2i, orr, oi);
@@ -3162,8 +3174,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 uint32_t h[4], l[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) split_h(v[u][0][r], h[r], l[r]);
-                const h8 xh = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
-                const h8 xl = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                h8 xh = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
+                h8 xl = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                mma_operand_fence(xh, xl);
                 mma33(tr[u], ti[u], xl, dc.brh, xh, dc.brl, xh, dc.brh, xl, dc.bih, xh, dc.bil, xh, dc.bih);
             }
 #pragma unroll
