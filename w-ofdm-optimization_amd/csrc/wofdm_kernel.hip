@@ -159,7 +159,8 @@ __device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
 // asm.  One wait state that both operand halves pass through; tests/test_code_layout.py checks the built library.
 __device__ __forceinline__ void mma_operand_fence(h8 &hi, h8 &lo)
 {
-    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));
+    // (not volatile: ordered by its operands alone -- as a volatile statement it cost N = 512 one per cent)
+    asm("s_nop 0" : "+v"(hi), "+v"(lo));
 }
 __device__ __forceinline__ v2f join_h(uint32_t hi, uint32_t lo)
 {
