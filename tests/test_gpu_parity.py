@@ -60,7 +60,7 @@ def _expected_layout(st, n_fft, S):
             return 4
         if 4 * B <= 64 * 20:
             return 5
-    if n_fft >= 512 and B >= n_fft and B % 4 == 0 and B <= 128 * (9 if n_fft == 1024 else 5):
+    if n_fft >= 512 and B >= n_fft and B % 2 == 0 and B <= 128 * (9 if n_fft == 1024 else 5):
         return 12
     return 2 if (n_fft <= 256 and S % 2 == 0 and 2 * B <= 64 * (2 * (n_fft // 64) + 2)) else 1
 
@@ -256,6 +256,36 @@ def test_production_and_instrumented_kernels_count_the_same(channels, system, n_
     assert np.array_equal(prod[:, 1], inst[:, 1]) and np.array_equal(prod[:, 3], inst[:, 3])
     assert prod[:, 0].min() > 50, prod
     assert np.abs(prod - inst).max() <= 2, (prod, inst)
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k,opts,layout", [("WOLA", 512, 30, 4, {}, 12), ("CP", 512, 10, 2, {}, 12), ("WOLA", 1024, 30, 6, {}, 12),
+                                                            ("WOLA", 512, 30, 4, {"dft_valu": 1}, 8), ("wtx", 512, 14, 6, {}, 12)])
+@pytest.mark.parametrize("S", [16, 7])
+def test_even_strides_that_are_not_multiples_of_four(channels, system, n_fft, cp, k, opts, layout, S):
+    """One symbol per wave with the FIR on the matrix pipe (layouts 8, 12; 9 and 15 in test_gpu_channel_mask.py): a stride of 2 mod 4
+    puts the end of a symbol inside a 16-byte operand row, which fir_load cuts word by word."""
+    st = W.make_structure(system, n_fft, cp)
+    assert st.stride % 4 == 2
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.array([8.0 + 3 * (k - 2), 20.0 + 3 * (k - 2)], np.float32)
+    h = channels[5:7].astype(np.complex64)
+    seed, off, F = 31, 3, 5
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True)
+    want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        for key, val in opts.items():
+            plan.set_option(key, val)
+        assert plan.kernel_id() == (layout, 0)
+        got = plan.run(off, F)
+        gc, gd = plan.dump_frame(1, 4)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    assert np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)).max() <= 2, (got[..., 0], want[..., 0])
+    lab, noise = O.gen_labels(osys, seed, 1, 4), O.gen_noise(osys, seed, 1, 4)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h[1].astype(np.complex128), float(snrs[0]), lab, noise, dump=True)
+    for stage in ("tx", "rx", "Y"):
+        a, b = np.asarray(gd[stage]).ravel(), np.asarray(od[stage]).ravel()
+        assert np.abs(a[:b.size] - b).max() / np.abs(b).max() < 2e-5, stage
 
 
 @pytest.mark.parametrize("S", [2, 5, 7, 12])

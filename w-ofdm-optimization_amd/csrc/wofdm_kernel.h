@@ -146,15 +146,16 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
-    // one symbol per wave, matrix-pipe FIR: 16-byte operand rows must not straddle a symbol (B % 4)
-    if (firm && plain && n_fft >= 512 && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
+    // one symbol per wave, matrix-pipe FIR: a lane's two samples of a tile are one Philox block and one 16-byte store: even strides
+    // (a 16-byte operand row that straddles the end of a symbol -- B = 2 mod 4 -- is cut word by word, fir_load)
+    if (firm && plain && n_fft >= 512 && B % 2 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
-// layout of the Tx-mask variants: 9 where the matrix-pipe FIR fits (16-byte operand rows must not straddle a symbol), else 1
+// layout of the Tx-mask variants: 9 where the matrix-pipe FIR fits (even strides, as above), else 1
 static inline int wofdm_spw_masked(int n_fft, int B, bool firm)
 {
-    return (firm && B >= n_fft && B % 4 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) ? 9 : 1;
+    return (firm && B >= n_fft && B % 2 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) ? 9 : 1;
 }
 
 // float2 elements of noise scratch per workgroup (0: not used for this DFT length)

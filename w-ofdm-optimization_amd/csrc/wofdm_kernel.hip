@@ -2531,13 +2531,24 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 o.h0 = ld16(ph0); o.h1 = ld16(ph1); o.l0 = ld16(pl0); o.l1 = ld16(pl1);
                 // (layout 9: a short row -- N < 512 -- can end in ANY tile, and the rows behind it may still hold fp32 data)
                 if ((FIR8M || G == NT - 1) && !trailing) {
-                    // The block that holds the symbol's last samples may reach up to 4 samples past
-                    // them (B is a multiple of 4, not of 8).  The Toeplitz entries that meet those are
+                    // The block that holds the symbol's last samples may reach up to 7 samples past
+                    // them (B is even, not a multiple of 8).  The Toeplitz entries that meet those are
                     // zero, but the words there are another row's (possibly the next wave's scratch:
-                    // any bit pattern, NaN included) -- zero them.
-                    const h8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (q0 >= B) { o.h0 = zr; o.l0 = zr; }
-                    if (q0 + 16 >= B) { o.h1 = zr; o.l1 = zr; }
+                    // any bit pattern, NaN included) -- zero them, word by word where a 16-byte row straddles the end
+                    // (B = 2 mod 4).
+                    auto clip = [&](h8 &hh, h8 &ll, int q) {
+                        const int r = B - q;                              // words of this row that are the symbol's
+                        if (r < 4) {
+                            u4 a = __builtin_bit_cast(u4, hh), c = __builtin_bit_cast(u4, ll);
+                            if (r < 1) { a.x = 0u; c.x = 0u; }
+                            if (r < 2) { a.y = 0u; c.y = 0u; }
+                            if (r < 3) { a.z = 0u; c.z = 0u; }
+                            a.w = 0u; c.w = 0u;
+                            hh = __builtin_bit_cast(h8, a); ll = __builtin_bit_cast(h8, c);
+                        }
+                    };
+                    clip(o.h0, o.l0, q0);
+                    clip(o.h1, o.l1, q0 + 16);
                 }
             } else {
                 // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
