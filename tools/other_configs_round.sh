@@ -15,6 +15,8 @@ echo; echo "## tools/full_reference_sweep.py"
 timeout -k 10 300 python tools/full_reference_sweep.py 2>&1 | grep -v amdgpu.ids
 echo; echo "## tools/bench_channel_mask.py (row f1)"
 timeout -k 10 300 python tools/bench_channel_mask.py 2>&1 | grep -v amdgpu.ids
+echo; echo "## tools/bench_even_strides.py (strides of 2 mod 4 with one symbol per wave: matrix-pipe layouts against layout 1)"
+timeout -k 10 300 python tools/bench_even_strides.py 2>&1 | grep -v amdgpu.ids
 echo; echo "## tools/bench_interference.py (row f2)"
 timeout -k 10 300 python tools/bench_interference.py 2>&1 | grep -v amdgpu.ids
 } > $OUT
