@@ -4,7 +4,8 @@ import numpy as np
 spec=importlib.util.spec_from_file_location('fz',os.path.join(R,'tests/test_gpu_fuzz.py')); m=importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 ch=np.load(os.path.join(R,"tests/golden/channels_vehA.npz"))["h"]
 bad=0; n=0
-for seed in (1,2,3,4):
+seeds = range(1, 1 + int(sys.argv[1])) if len(sys.argv) > 1 else (1, 2, 3, 4)      # python tools/fuzz_big.py [n_seeds]: 100 geometries each
+for seed in seeds:
     for case in m._cases(100, seed=seed*7919):
         n+=1
         try:
