@@ -136,8 +136,7 @@ int configure(wofdm_plan *pl)
                                  : (pl->has_alloc ? WOFDM_VAR_ALLOC : WOFDM_VAR_PLAIN);
     const bool masked = var == WOFDM_VAR_TXMASK || var == WOFDM_VAR_TXFFT;
     const bool firm = !pl->fir_valu;
-    // (layouts 13 / 14 -- N = 64, 128 with the transforms on the matrix pipe -- are built without the allocation variant)
-    const bool mdft = !pl->dft_valu && !(var == WOFDM_VAR_ALLOC && g.N <= 128);
+    const bool mdft = !pl->dft_valu;
     int spw = masked ? wofdm_spw_masked(g.N, g.B, firm) : wofdm_spw(g.N, g.S, g.B, true, firm, mdft);
     // (layout 15: the fast-convolution mask at N = 256 with all four transforms on the matrix pipe)
     if (var == WOFDM_VAR_TXFFT && g.N == 256 && spw == 9 && mdft && WOFDM_TXFFT_LEN == 1024) spw = 15;
@@ -519,6 +518,16 @@ int wofdm_plan_set_allocation(wofdm_plan *pl, const uint8_t *active)
             if (N == 256) {
                 const int l = n & 15, t = n >> 4;
                 words[(size_t)(NQ + 16 * (t & 3) + l)] |= 0x80u << (8 * (t >> 2));
+            }
+            if (N <= 128) {
+                // [NQ, NQ + 256): layouts 13 / 14, word 64 t + lane (set t), byte j <-> subcarrier N/16 (lane / 16 + 4 j) + c,
+                // c = 4 (t % (N / 64)) + lane % 4
+                const int sc = N / 16, scs = sc / 4;
+                for (int t = 0; t < 4; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            if (sc * (lane / 16 + 4 * j) + 4 * (t % scs) + (lane & 3) == n)
+                                words[(size_t)(NQ + 64 * t + lane)] |= 0x80u << (8 * j);
             }
             if (N >= 512 || N == 256) {
                 // (N = 256, layout 15: one set, behind the quarter-wave part)

@@ -1109,7 +1109,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // workgroups, three of them per CU at up to 168 VGPRs
     constexpr bool QW = SPW == 4 && !MDFT && !MDS;
     static_assert(!(QW || MDFT) || (N == 256 && VAR <= 1), "the four-symbol layouts are built for N = 256 without Tx mask");
-    static_assert(!MDS || ((N == 64 || N == 128) && VAR == 0), "layouts 13 / 14 are built for N = 64, 128, every subcarrier loaded");
+    static_assert(!MDS || ((N == 64 || N == 128) && VAR <= 1), "layouts 13 / 14 are built for N = 64, 128, without Tx mask");
     constexpr int VS = QW ? 1 : (MDS ? 1 : SPW), VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, LAY>::RB, NBK = fir_geo<N, LAY>::NBK;
     constexpr bool EVEN = fir_geo<N, LAY>::EVEN;
@@ -1486,6 +1486,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
                 const uint32_t *bw = reinterpret_cast<const uint32_t *>(row(sr));
                 li[t] = 0;
+                // byte j of the word: 0x80 when subcarrier SC (g + 4 j) + c is NOT loaded (second part of the table: this layout's
+                // order, one word per set and lane); the flag rides in the label byte down to phase D
+                uint32_t am = 0;
+                if constexpr (ALLOC) am = g_amask[NQ + 64 * t + lane] & 0x80808080u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = SC * (lg + 4 * j) + c;
@@ -1498,12 +1502,16 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                     li[t] |= Lb << (8 * j);
                     xw[t][j] = qlw[Lb];
+                    if constexpr (ALLOC) {
+                        if ((am >> (8 * j)) & 0x80u) xw[t][j] = 0u;
+                    }
                     if (DUMP) {
                         const hpair hw = __builtin_bit_cast(hpair, xw[t][j]);
                         if (p.dump.labels_tx) p.dump.labels_tx[(s0 + sr) * N + n] = (uint8_t)Lb;
                         if (p.dump.X) p.dump.X[(s0 + sr) * N + n] = make_float2((float)hw.y * qscale, (float)hw.x * qscale);
                     }
                 }
+                if constexpr (ALLOC) li[t] |= am;
             }
             // the labels once through the wave's (still unused) rows into OUTPUT order for phase D: one byte per subcarrier
             uint8_t *lbytes = reinterpret_cast<uint8_t *>(row(0));
@@ -3046,7 +3054,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const hpair hw = __builtin_bit_cast(hpair, qlw[(labo[pp] >> (8 * e)) & lmask]);
-                            const float x0r = (float)hw.y, x0i = (float)hw.x;
+                            float x0r = (float)hw.y, x0i = (float)hw.x;
+                            if constexpr (ALLOC) {
+                                if ((labo[pp] >> (8 * e)) & 0x80u) { x0r = 0.f; x0i = 0.f; }      // G = 0 there
+                            }
                             const float y0r = yr[pp][e], y0i = yi[pp][e];
                             const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
                             gr[e] = (x0r * y0r + x0i * y0i) * inv;
@@ -3340,6 +3351,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const uint32_t cw = (iw << half) | qw;
                 const uint32_t gw = cw ^ ((cw >> 1) & GM);
                 uint32_t diff = (gw ^ labo[t]) & LM;
+                if constexpr (ALLOC) diff &= ~(((labo[t] >> 7) & 0x01010101u) * 0xFFu);   // bit 7 = not loaded: not counted
                 if (s == 0) diff = 0;                               // the pilot symbol is not counted
                 bit_err += __popc(diff);
                 sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
@@ -3776,8 +3788,10 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
 {
     if (spw == 1) return pick_var<N, K, 1>(mode, var);
     if constexpr (N == 64 || N == 128) {
-        if (spw == 13 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 13, WOFDM_VAR_PLAIN>(mode);
-        if (spw == 14 && var == WOFDM_VAR_PLAIN) return pick_mode<N, K, 14, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 13 && var <= WOFDM_VAR_ALLOC)
+            return var ? pick_mode<N, K, 13, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 13, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 14 && var <= WOFDM_VAR_ALLOC)
+            return var ? pick_mode<N, K, 14, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 14, WOFDM_VAR_PLAIN>(mode);
     }
     if (spw == 9) {
         if constexpr (N <= WOFDM_TXMASK_MAX_N) {
