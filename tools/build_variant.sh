@@ -13,7 +13,7 @@ objs=""
 for o in wofdm_kernel_n*_k*.o; do
   n=$(echo $o | sed 's/.*_n\([0-9]*\)_k.*/\1/'); k=$(echo $o | sed 's/.*_k\([0-9]*\)\.o/\1/')
   if echo " $NS " | grep -q " $n " && echo " $KS " | grep -q " $k "; then
-    sched=""; { [ "$n" = 512 ] || [ "$n" = 1024 ]; } && sched="-mllvm -amdgpu-sched-strategy=max-ilp"      # (as the Makefile's SCHED_512 / SCHED_1024)
+    sched=""; { [ "$n" = 64 ] || [ "$n" = 512 ] || [ "$n" = 1024 ]; } && sched="-mllvm -amdgpu-sched-strategy=max-ilp"      # (as the Makefile's SCHED_64 / SCHED_512 / SCHED_1024)
     /opt/rocm/bin/hipcc $FLAGS $sched "$@" -DWOFDM_TU_N=$n -DWOFDM_TU_K=$k -c wofdm_kernel.hip -o ../../ab/obj_$name/$o &
     objs="$objs ../../ab/obj_$name/$o"
   else

@@ -48,7 +48,7 @@ def classify(op):
 
 def compile_tu(n, k, extra):
     out = os.path.join(tempfile.mkdtemp(), "k.s")
-    sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if n in ("512", "1024") else []      # (the Makefile's SCHED_512 / SCHED_1024)
+    sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if n in ("64", "512", "1024") else []      # (the Makefile's SCHED_64 / SCHED_512 / SCHED_1024)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                     "-fno-slp-vectorize", *sched, "-DWOFDM_TU_N=" + n, "-DWOFDM_TU_K=" + k, *extra, "-S",
                     "--cuda-device-only", "-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
