@@ -159,15 +159,15 @@ def test_mfma_chains_sit_in_one_line_and_no_kernel_uses_flat_instructions():
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-readelf")) and shutil.which("objcopy")),
                     reason="needs the built library and the ROCm LLVM tools")
 def test_committed_kernel_table_describes_the_built_library():
-    """profiles/r03_kernel_table.json (tools/kernel_table.py) lists registers / spills / ScratchSize per instantiation;
+    """profiles/kernel_table.json (tools/kernel_table.py) lists registers / spills / ScratchSize per instantiation;
     tests/test_gpu_parity.py::test_every_spilling_production_kernel takes its cases from it."""
     import json
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_table
     built = kernel_table.table(LIB)
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_table.json")))["kernels"]
+    committed = json.load(open(os.path.join(ROOT, "profiles", "kernel_table.json")))["kernels"]
     key = lambda r: (r["n_fft"], r["k"], r["layout"], r["inject"], r["dump"], r["var"])   # noqa: E731
     assert len(built) == len(committed) == 708
     spill = lambda rows: sorted(key(r) for r in rows if r["private_segment_fixed_size"] > 0)   # noqa: E731
-    assert spill(built) == spill(committed), "rebuild the table: python tools/kernel_table.py > profiles/r03_kernel_table.json"
+    assert spill(built) == spill(committed), "rebuild the table: python tools/kernel_table.py > profiles/kernel_table.json"

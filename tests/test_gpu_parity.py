@@ -566,7 +566,7 @@ def test_production_kernels_sharp_parity(channels, system, n_fft, cp, k, S):
 
 # ---------------------------------------------------------------------------------------------
 # Every production (non-instrumented) instantiation of the frame kernel that the compiler gave a
-# non-zero ScratchSize -- the committed build table profiles/r03_kernel_table.json
+# non-zero ScratchSize -- the committed build table profiles/kernel_table.json
 # (tools/kernel_table.py) -- is run once at sharp-parity size: register spills inside the divergent
 # regions of these kernels are the hazard DESIGN.md section 4 records, and a reload of the wrong lanes
 # would move the error count by hundreds.  Generate and injected mode, plain / allocation / both
@@ -574,7 +574,7 @@ def test_production_kernels_sharp_parity(channels, system, n_fft, cp, k, S):
 def _spilling_kernels():
     import json
     import os
-    path = os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_kernel_table.json")
+    path = os.path.join(os.path.dirname(__file__), "..", "profiles", "kernel_table.json")
     rows = json.load(open(path))["kernels"]
     return [(r["n_fft"], r["k"], r["layout"], r["inject"], r["var"]) for r in rows
             if not r["dump"] and r["private_segment_fixed_size"] > 0]

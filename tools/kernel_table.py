@@ -2,7 +2,7 @@
 """Developer tool (build container): registers / spills / scratch of EVERY instantiation of the frame kernel, read
 from the metadata notes of the BUILT library (what ships, per-translation-unit compiler flags included).
 
-    python tools/kernel_table.py > profiles/r03_kernel_table.json
+    python tools/kernel_table.py > profiles/kernel_table.json
 
 tests/test_gpu_parity.py reads the committed table and runs the sharp-parity case for every production
 (non-instrumented) instantiation whose ScratchSize is not zero; tests/test_code_layout.py checks that the table still

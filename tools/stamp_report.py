@@ -51,5 +51,6 @@ print("N=%d k=%d: %.2f ms, %d workgroups x %d waves; mean cycles per wave %.3e" 
 for i in order:
     nm = names[i]
     sh = st_[:, :, i] / tot
-    print("  %-22s all waves %5.1f %%   wave 0 %5.1f %%   last wave %5.1f %%"
-          % (nm, 100 * sh.mean(), 100 * sh[:, 0].mean(), 100 * sh[:, -1].mean()))
+    per_frame = st_[:, :, i].mean() / (frames * 12.0 / grid)          # cycles per frame of one wave
+    print("  %-22s all waves %5.1f %%   wave 0 %5.1f %%   last wave %5.1f %%   %7.0f cycles/frame"
+          % (nm, 100 * sh.mean(), 100 * sh[:, 0].mean(), 100 * sh[:, -1].mean(), per_frame))

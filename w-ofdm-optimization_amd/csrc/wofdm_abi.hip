@@ -142,9 +142,14 @@ int configure(wofdm_plan *pl)
     if (var == WOFDM_VAR_TXFFT && g.N == 256 && spw == 9 && mdft && WOFDM_TXFFT_LEN == 1024) spw = 15;
     if (pl->max_spw > 0 && wofdm_nsym(spw, g.N) > pl->max_spw)
         spw = (pl->max_spw == 1) ? 1 : wofdm_spw(g.N, g.S, g.B, false);
+    // (WOFDM_DEV_LDS_PAD: developer builds only -- unused LDS bytes per workgroup, to measure how the rate depends on the
+    // number of workgroups a CU holds; never defined in the shipped library)
+#ifndef WOFDM_DEV_LDS_PAD
+#define WOFDM_DEV_LDS_PAD 0
+#endif
     const unsigned lds = wofdm_lds_bytes(g.N, g.T, spw, g.S, g.B)
                          + (var == WOFDM_VAR_TXMASK ? wofdm_txmask_lds_bytes(g.N) : 0u)
-                         + (var == WOFDM_VAR_TXFFT && spw != 15 ? wofdm_txfft_lds_bytes() : 0u);
+                         + (var == WOFDM_VAR_TXFFT && spw != 15 ? wofdm_txfft_lds_bytes() : 0u) + (unsigned)(WOFDM_DEV_LDS_PAD);
     if (lds > 160u * 1024u)
         return fail(WOFDM_E_UNSUPPORTED, "frame needs %u bytes of LDS (160 KiB per workgroup)", lds);
     wofdm_kernel_fn fn[4];

@@ -63,6 +63,11 @@
 #define WOFDM_NOISE_KEEP_TILES 6
 #endif
 
+// layouts 10 ... 15, generate mode: the FIR tile as a hand-placed pipeline (MFMAs between the Philox rounds; see phase B)
+#ifndef WOFDM_TILE_PIPELINE
+#define WOFDM_TILE_PIPELINE 1
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -81,7 +86,13 @@ namespace {
         stamp_t = now_;                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                     \
     } while (0)
+#ifdef WOFDM_STAMP_A4                     /* the Tx write split into slots 8..10 instead of A1..A3 (developer probe) */
+#define STAMPF(slot) do { if ((slot) > 10) STAMP(slot); } while (0)
+#define STAMPX(slot) STAMP(slot)
+#else
 #define STAMPF(slot) STAMP(slot)          /* finer marks inside the phases (slots 8..15) */
+#define STAMPX(slot) do { } while (0)
+#endif
 #ifdef WOFDM_STAMP_MASK                   /* the Tx mask stage split into slots 13..15 instead of phase C */
 #define STAMPC(slot) do { } while (0)
 #define STAMPM(slot) STAMP(slot)
@@ -92,6 +103,7 @@ namespace {
 #else
 // (a comment in the assembly: tools/isa_mix.py splits the frame loop's instruction mix at these)
 #define STAMP(slot) asm volatile("; wofdm_mark " #slot)
+#define STAMPX(slot) do { } while (0)
 #ifdef WOFDM_MMARK      /* developer builds (hipcc -S): the finer marks as comments too */
 #define STAMPF(slot) asm volatile("; wofdm_mmark " #slot)
 #define STAMPC(slot) asm volatile("; wofdm_mmark " #slot)
@@ -137,6 +149,9 @@ __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 // 2^-21, four times coarser than an fp32 product -- on whole frames, against fp64 arithmetic, conv is off by 1.3e-7
 // (rms) of the frame's rms, the fp32 VALU form by 1.1e-7: both at the rounding floor of the fp32 stages around them
 // (tests/test_gpu_parity.py::test_fir_precision_matrix_pipe_vs_valu).
+#ifndef WOFDM_SPLIT_MIX32
+#define WOFDM_SPLIT_MIX32 1
+#endif
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef h2 hpair;                  // (phase C has a local named h2)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -148,10 +163,21 @@ __device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
     hi = __builtin_bit_cast(uint32_t, h);
     // lo = f16(y - float(hi)), one mixed-precision fma per half (the difference is exact in fp32, rounded once):
     // three instructions per sample instead of five (two converts back, a packed subtract, a packed convert)
+#if WOFDM_SPLIT_MIX32
+    // (round 4) the two differences as v_fma_mix_f32 -- 4.3 cycles of vector issue each, where the f16-destination forms
+    // v_fma_mixlo / mixhi_f16 take 8.3 like a transcendental and read their own destination (tools/ubench/valu_dep.hip) --
+    // and one more packed convert: four instructions, 17 cycles instead of three and 21, and a dependent chain of three, not
+    // of three with two slow links.  Same arithmetic: the difference is exact in fp32 and rounded once.
+    float dx, dy;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dx) : "v"(hi), "v"(y.x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dy) : "v"(hi), "v"(y.y));
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(mk(dx, dy), h2));
+#else
     uint32_t l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(y.x));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(y.y));
     lo = l;
+#endif
 }
 // A matrix operand built from split_h words must not reach its MFMA straight from the last v_fma_mixhi_f16: the MFMA does not see
 // what the vector instruction DIRECTLY in front of it wrote (tools/ubench/mfma_after_mix.hip: every such result wrong, one instruction
@@ -2055,6 +2081,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
+            STAMPX(9);
             // prefix: samples t >= N - mu once more, N words in front
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2073,6 +2100,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         }
                     }
             }
+            STAMPX(10);
             // suffix: samples t < rho once more, N words behind -- in the fall tail from position B on
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2094,6 +2122,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             };
             const bool small = mu <= 48 && rho <= 48;
+            STAMPX(8);
             if (body_tail) { if (small) txm(std::true_type{}, std::true_type{}); else txm(std::true_type{}, std::false_type{}); }
             else { if (small) txm(std::false_type{}, std::true_type{}); else txm(std::false_type{}, std::false_type{}); }
         } else if constexpr (FIRQ) {
@@ -2632,11 +2661,72 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             bool valid = FULLT || jr < LW;
             if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
             v2f n0, n1;
+            f4 d;
+            if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE) {
+                // The tile as a hand-placed pipeline (round 4).  A wave issues a DEPENDENT vector instruction every 8.3 cycles
+                // at best and an independent one every 4.3 (tools/ubench/valu_dep.hip); the six MFMAs of the chain are dependent
+                // (16 cycles apart), their operand rows take an LDS round trip, and a vector instruction must neither read the
+                // chain's result nor WRITE one of its operand registers for 12 wait states behind the last MFMA (mma33).  Left
+                // to the compiler the tile was: six MFMAs back to back, twelve idle wait states, THEN the noise draw, with the
+                // next tile's rows requested ten instructions ahead of their use -- 499 cycles per tile for a wave on its own,
+                // 274 of them vector issue (profiles/r04_stamp_occ.txt).  Here the Philox rounds of the tile's noise pair sit
+                // BETWEEN the MFMAs (two rounds = eight instructions = 34 cycles per gap: the chain never waits), the Box-Muller
+                // transform (18 instructions) behind the last one takes the place of the wait states, the guard behind it keeps
+                // the operands allocated up to there without spending a cycle, and the next tile's rows are requested a whole
+                // tile ahead.  tests/test_code_layout.py checks the distances in the built code.
+                bops o = bq;
+                if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
+                uint32_t c0 = (uint32_t)(jw + jr) >> 1, c1 = f_lo, c2 = f_hi, c3 = (WOFDM_STREAM_NOISE << 28) | cell;
+                uint32_t k0 = key0, k1 = key1;
+                auto rounds2 = [&]() {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+                        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+                        const uint32_t m0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+                        const uint32_t m2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+                        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = m0; c2 = m2;
+                        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+                    }
+                };
+                // The order is pinned by DEPENDENCIES, not by scheduling hints: an MFMA builtin and the Philox arithmetic are pure, so
+                // every IR pass may move them across a sched_barrier (an instrumented instantiation came out as six MFMAs back
+                // to back with the noise draw behind the guard -- and an operand register overwritten two instructions behind
+                // its MFMA: tests/test_code_layout.py caught it).  Each TIE is an empty volatile asm statement through which
+                // the chain's accumulator AND the Philox words pass: what produces its inputs comes before it, what consumes
+                // its outputs after it, and volatile statements keep their order.
+                asm volatile("" : "+v"(o.h0), "+v"(c0));                                   // (the tile starts here)
+#define WOFDM_TIE() asm volatile("" : "+v"(d), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3))
+                const f4 z = {0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], o.h0, z, 0, 0, 0);
+                rounds2();
+                WOFDM_TIE();
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[3], o.h1, d, 0, 0, 0);
+                rounds2();
+                WOFDM_TIE();
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.l0, d, 0, 0, 0);
+                rounds2();
+                WOFDM_TIE();
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.l1, d, 0, 0, 0);
+                rounds2();
+                WOFDM_TIE();
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], o.h0, d, 0, 0, 0);
+                rounds2();
+                WOFDM_TIE();
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2], o.h1, d, 0, 0, 0);
+                WOFDM_TIE();                      // the Box-Muller transform starts BEHIND the last MFMA ...
+#undef WOFDM_TIE
+                n0 = box_muller<false>(c0, c1);
+                n1 = box_muller<false>(c2, c3);
+                // ... and ends in front of the guard: 18 vector instructions (two of them per 16 cycles at best) between the last
+                // MFMA and the first instruction that may read its result or write one of its operand registers
+                asm volatile("" : "+v"(d), "+v"(n0), "+v"(n1) : "v"(o.h0), "v"(o.h1), "v"(o.l0), "v"(o.l1), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]));
+            } else {
             // the six MFMAs go first and run on the matrix pipe under the noise draw of the same tile,
             // the next tile's operand rows are requested in between
             if constexpr (!PREFETCH) bq = fir_load(jw, G, false);
             const bops bcur = bq;
-            const f4 d = fir_mma(bcur);
+            d = fir_mma(bcur);
             if constexpr (PREFETCH) {
                 if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
             }
@@ -2650,6 +2740,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
+            }
             }
             const v2f c0 = mk(d.x, d.y), c1 = mk(d.z, d.w);
             if (RENOISE && (INJECT || G >= NKEEP)) {
