@@ -68,6 +68,11 @@
 #define WOFDM_TILE_PIPELINE 1
 #endif
 
+// layouts 10, 11: the 256-point transforms as a pipeline over the wave's four symbols (phases A and C)
+#ifndef WOFDM_MDFT_PIPELINE
+#define WOFDM_MDFT_PIPELINE 1
+#endif
+
 #ifndef WOFDM_MIN_WAVES_PER_SIMD
 #define WOFDM_MIN_WAVES_PER_SIMD 4      // one 16-wave workgroup per CU -> 128 VGPRs per lane
 #endif
@@ -691,6 +696,35 @@ __device__ __forceinline__ void mma22(f4 &re, f4 &im, h8 a, h8 b0, h8 b1, h8 b2,
     asm volatile(WOFDM_MMA_TAIL : "+v"(r), "+v"(i) : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
     re = r; im = i;
 }
+// The same MFMAs WITHOUT the statement behind them (round 4): for callers that place the next symbol's vector work behind the chain
+// themselves and then guard it (WOFDM_TIE / WOFDM_GUARD below) -- the wait states are spent on instructions that had to be issued anyway.
+__device__ __forceinline__ void mma33_issue(f4 &re, f4 &im, h8 a0, h8 b0, h8 a1, h8 b1, h8 a2, h8 b2,
+                                            h8 a3, h8 b3, h8 a4, h8 b4, h8 a5, h8 b5)
+{
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, z, 0, 0, 0);
+    f4 i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, b3, z, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4, b4, i, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a5, b5, i, 0, 0, 0);
+    re = r; im = i;
+}
+__device__ __forceinline__ void mma22_issue(f4 &re, f4 &im, h8 a, h8 b0, h8 b1, h8 b2, h8 b3)
+{
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, z, 0, 0, 0);
+    f4 i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, z, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, r, 0, 0, 0);
+    i = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b3, i, 0, 0, 0);
+    re = r; im = i;
+}
+// Order by dependencies (MFMA builtins and vector arithmetic are pure: scheduling hints do not bind the IR passes; see the FIR tile in
+// phase B).  WOFDM_TIE2: an empty volatile statement that a chain's two accumulators and the inputs of the vector work that is to run
+// BEHIND the chain pass through.  The guard that closes such a group is written out at its place: it takes the results of that vector
+// work as in-out operands and the chain's accumulators and ALL its operands as inputs, so that the operands stay allocated, and apart
+// from the accumulators, up to there -- two dozen vector instructions behind the last MFMA instead of twelve idle wait states.
+#define WOFDM_TIE2(r, i, a, b) asm volatile("" : "+v"(r), "+v"(i), "+v"(a), "+v"(b))
 // sample x window value, as two plain multiplies the compiler cannot re-pack: where window values arrive as pairs (the
 // consecutive elements of layout 12) it multiplies the second sample by the pair's HIGH half -- v_pk_mul_f32 with an
 // op_sel swizzle, the one instruction form these kernels must not contain (mma33)
@@ -1929,7 +1963,38 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPF(9);
-        if constexpr (MDFT) {
+        if constexpr (MDFT && WOFDM_MDFT_PIPELINE) {
+            // The transform as a pipeline over the wave's four symbols (round 4): the sixteen MFMAs of stage 1 are issued at once,
+            // then every group is "the six MFMAs of symbol u's second stage, and BEHIND them the twiddle and the f16 split of symbol
+            // u + 1" (26 vector instructions, 110 cycles, while the chain takes 96 on the matrix pipe) -- the guard behind that work
+            // needs no wait states.  Only the last symbol's chain, which has nothing behind it, ends in the twelve.
+            const mdft_consts dc = mdft_load(dce);
+            f4 tr[4], ti[4];
+            h8 xa[4], th[4], tl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xa[u] = __builtin_bit_cast(h8, (u4){xw[u][0], xw[u][1], xw[u][2], xw[u][3]});
+                mma22_issue(tr[u], ti[u], xa[u], dc.brl, dc.brh, dc.bil, dc.bih);
+            }
+            asm volatile("" : "+v"(tr[0]), "+v"(ti[0]), "+v"(tr[1]), "+v"(ti[1]), "+v"(tr[2]), "+v"(ti[2]), "+v"(tr[3]), "+v"(ti[3]));
+            mdft_twiddle(tr[0], ti[0], dc.twr, dc.twi);
+            mdft_split4(tr[0], ti[0], th[0], tl[0]);
+            asm volatile("" : "+v"(th[0]), "+v"(tl[0]) : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(dc.brl), "v"(dc.brh), "v"(dc.bil),
+                         "v"(dc.bih), "v"(tr[1]), "v"(ti[1]), "v"(tr[2]), "v"(ti[2]), "v"(tr[3]), "v"(ti[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mma33_issue(xr[u], xi[u], dc.arh, tl[u], dc.arl, th[u], dc.arh, th[u], dc.aih, tl[u], dc.ail, th[u], dc.aih, th[u]);
+                if (u < 3) {
+                    WOFDM_TIE2(xr[u], xi[u], tr[u + 1], ti[u + 1]);
+                    mdft_twiddle(tr[u + 1], ti[u + 1], dc.twr, dc.twi);
+                    mdft_split4(tr[u + 1], ti[u + 1], th[u + 1], tl[u + 1]);
+                    asm volatile("" : "+v"(th[u + 1]), "+v"(tl[u + 1]) : "v"(th[u]), "v"(tl[u]), "v"(xr[u]), "v"(xi[u]), "v"(dc.arh), "v"(dc.arl),
+                                 "v"(dc.aih), "v"(dc.ail));
+                } else {
+                    asm volatile(WOFDM_MMA_TAIL : "+v"(xr[u]), "+v"(xi[u]) : "v"(th[u]), "v"(tl[u]), "v"(dc.arh), "v"(dc.arl), "v"(dc.aih), "v"(dc.ail));
+                }
+            }
+        } else if constexpr (MDFT) {
             const mdft_consts dc = mdft_load(dce);
             f4 tr[4], ti[4];
 #pragma unroll
@@ -3280,7 +3345,80 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPC(14);
-        if constexpr (MDFT) {
+        // the pilot is symbol slot 0 of wave 0, four subcarriers per lane; G = X0 / Y0 (X0 as the table's small integers:
+        // the demapper's levels are scaled to match) goes out as one 16-byte row of real and one of imaginary parts
+        auto pilot_mdft = [&]() {
+            f4 gr, gi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t Lb = (lab[0][0] >> (8 * j)) & 0xFFu;
+                const hpair hw = __builtin_bit_cast(hpair, qlw[Lb & lmask]);
+                float x0r = (float)hw.y, x0i = (float)hw.x;
+                if constexpr (ALLOC) {
+                    if (Lb & 0x80u) { x0r = 0.f; x0i = 0.f; }
+                }
+                const float y0r = yr[0][j], y0i = yi[0][j];
+                const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
+                gr[j] = (x0r * y0r + x0i * y0i) * inv;                 // X0 conj(Y0) / |Y0|^2
+                gi[j] = (x0i * y0r - x0r * y0i) * inv;
+            }
+            f4 *G4 = reinterpret_cast<f4 *>(G);
+            G4[lane] = gr;
+            G4[64 + lane] = gi;
+            if constexpr (RELAXF) {
+                wave_sync();
+                post_flag(&flags[16], iter, lane);
+            }
+        };
+        (void)pilot_mdft;
+        if constexpr (MDFT && WOFDM_MDFT_PIPELINE) {
+            // the same pipeline as in phase A, one stage longer: behind the first-stage chain of symbol u the split of symbol u + 1's
+            // received samples, behind that of symbol 3 the twiddle and split of symbol 0, then the second stage as there
+            const mdft_consts dc = mdft_load(dce);
+            f4 tr[4], ti[4];
+            h8 xh[4], xl[4], th[4], tl[4];
+            auto split_in = [&](int u) {
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split_h(v[u][0][r], h[r], l[r]);
+                xh[u] = __builtin_bit_cast(h8, (u4){h[0], h[1], h[2], h[3]});
+                xl[u] = __builtin_bit_cast(h8, (u4){l[0], l[1], l[2], l[3]});
+                mma_operand_fence(xh[u], xl[u]);
+            };
+            split_in(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mma33_issue(tr[u], ti[u], xl[u], dc.brh, xh[u], dc.brl, xh[u], dc.brh, xl[u], dc.bih, xh[u], dc.bil, xh[u], dc.bih);
+                if (u < 3) {
+                    asm volatile("" : "+v"(tr[u]), "+v"(ti[u]), "+v"(v[u + 1][0][0]), "+v"(v[u + 1][0][1]), "+v"(v[u + 1][0][2]), "+v"(v[u + 1][0][3]));
+                    split_in(u + 1);
+                    asm volatile("" : "+v"(xh[u + 1]), "+v"(xl[u + 1]) : "v"(xh[u]), "v"(xl[u]), "v"(tr[u]), "v"(ti[u]), "v"(dc.brh), "v"(dc.brl),
+                                 "v"(dc.bih), "v"(dc.bil));
+                } else {
+                    WOFDM_TIE2(tr[3], ti[3], tr[0], ti[0]);
+                    mdft_twiddle(tr[0], ti[0], dc.twr, dc.twi);
+                    mdft_split4(tr[0], ti[0], th[0], tl[0]);
+                    asm volatile("" : "+v"(th[0]), "+v"(tl[0]) : "v"(xh[3]), "v"(xl[3]), "v"(tr[3]), "v"(ti[3]), "v"(dc.brh), "v"(dc.brl), "v"(dc.bih),
+                                 "v"(dc.bil));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mma33_issue(yr[u], yi[u], dc.arh, tl[u], dc.arl, th[u], dc.arh, th[u], dc.aih, tl[u], dc.ail, th[u], dc.aih, th[u]);
+                // the pilot wave publishes the equaliser as soon as ITS symbol is through (behind the second symbol's chain), not
+                // after all four: the other waves waited for it 2.8 % of their time (profiles/r04_stamp_occ.txt)
+                if (u == 1 && wv == 0) pilot_mdft();
+                if (u < 3) {
+                    WOFDM_TIE2(yr[u], yi[u], tr[u + 1], ti[u + 1]);
+                    mdft_twiddle(tr[u + 1], ti[u + 1], dc.twr, dc.twi);
+                    mdft_split4(tr[u + 1], ti[u + 1], th[u + 1], tl[u + 1]);
+                    asm volatile("" : "+v"(th[u + 1]), "+v"(tl[u + 1]) : "v"(th[u]), "v"(tl[u]), "v"(yr[u]), "v"(yi[u]), "v"(dc.arh), "v"(dc.arl),
+                                 "v"(dc.aih), "v"(dc.ail));
+                } else {
+                    asm volatile(WOFDM_MMA_TAIL : "+v"(yr[u]), "+v"(yi[u]) : "v"(th[u]), "v"(tl[u]), "v"(dc.arh), "v"(dc.arl), "v"(dc.aih), "v"(dc.ail));
+                }
+            }
+        } else if constexpr (MDFT) {
             const mdft_consts dc = mdft_load(dce);
             f4 tr[4], ti[4];
 #pragma unroll
@@ -3327,31 +3465,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
         }
         if constexpr (MDFT) {
-            // the pilot is symbol slot 0 of wave 0, four subcarriers per lane; G = X0 / Y0 (X0 as the table's small integers:
-            // the demapper's levels are scaled to match) goes out as one 16-byte row of real and one of imaginary parts
-            if (wv == 0) {
-                f4 gr, gi;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t Lb = (lab[0][0] >> (8 * j)) & 0xFFu;
-                    const hpair hw = __builtin_bit_cast(hpair, qlw[Lb & lmask]);
-                    float x0r = (float)hw.y, x0i = (float)hw.x;
-                    if constexpr (ALLOC) {
-                        if (Lb & 0x80u) { x0r = 0.f; x0i = 0.f; }
-                    }
-                    const float y0r = yr[0][j], y0i = yi[0][j];
-                    const float inv = __builtin_amdgcn_rcpf(y0r * y0r + y0i * y0i);
-                    gr[j] = (x0r * y0r + x0i * y0i) * inv;                 // X0 conj(Y0) / |Y0|^2
-                    gi[j] = (x0i * y0r - x0r * y0i) * inv;
-                }
-                f4 *G4 = reinterpret_cast<f4 *>(G);
-                G4[lane] = gr;
-                G4[64 + lane] = gi;
-                if constexpr (RELAXF) {
-                    wave_sync();
-                    post_flag(&flags[16], iter, lane);
-                }
-            }
+            // (with the transforms as a pipeline the pilot wave has published its equaliser already: see the second stage above)
+            if (wv == 0 && !WOFDM_MDFT_PIPELINE) pilot_mdft();
         } else if (QW && wv == 0) {
             // quarter-wave layout: the pilot symbol sits in lanes 0..15 of wave 0, and every other
             // wave waits for its equaliser.  Those 16 lanes only hand their Y0 and packed labels
