@@ -751,7 +751,7 @@ def test_back_to_back_mfma_chains_leave_the_neighbours_alone():
     """The assumption the FIR's chain rests on, checked on THIS GPU (tools/ubench/mfma_stall_victim.hip --quick): six
     in-place v_mfma_f32_16x16x32_f16 issued back to back -- up to 6 wait states between two of them -- never disturb packed
     op_sel arithmetic of the SIMD's other waves, even when those are the older (preferred) waves; 16 wait states between
-    the fifth and the sixth do (printed, not asserted: that part documents the hazard)."""
+    the fifth and the sixth do (asserted as well since round 4: the day this GPU family stops showing it, the test says so)."""
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "native", "mfma_stall_victim")
     assert os.path.exists(exe), "make -C tests/native"
@@ -764,6 +764,11 @@ def test_back_to_back_mfma_chains_leave_the_neighbours_alone():
         if int(row["gap"]) <= 6:
             assert int(row["bystanders_bad"]) == 0, row
         else:
+            # the hazard side is asserted too (round 4): if a GPU / driver / firmware stops showing it, this fails, and the
+            # contract that rests on it -- one frame kernel per GPU at a time, include/wofdm.h -- can be dropped.  Measured
+            # behaviour of this silicon, not a documented rule (hazards 1 and 4).
+            assert int(row["bystanders_bad"]) > 0, ("16 wait states inside an MFMA chain no longer disturb the SIMD's other waves: "
+                                                    "revisit hazard 1 in DESIGN.md section 4", row)
             print("\n16 wait states inside the chain: %s wrong bystander values" % row["bystanders_bad"])
 
 
@@ -771,7 +776,7 @@ def test_mfma_trains_only_hit_op_sel_swizzles():
     """What layouts 10 / 11 rest on, checked on THIS GPU (tools/ubench/mfma_block_train.hip --quick): trains of MFMA blocks a few
     dozen cycles apart -- the matrix-pipe transforms -- leave every packed / mixed-precision instruction form those kernels
     contain exact in the SIMD's other waves (op_sel_hi broadcasts, neg, no modifier, v_cvt_pk_f16_f32 + v_fma_mix*), while
-    v_pk_add_f32 with an op_sel swizzle -- which they do not contain, tests/test_code_layout.py -- is hit (printed, not asserted)."""
+    v_pk_add_f32 with an op_sel swizzle -- which they do not contain, csrc/verify_code_layout.py -- is hit (asserted too)."""
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "native", "mfma_block_train")
     assert os.path.exists(exe), "make -C tests/native"
@@ -784,6 +789,9 @@ def test_mfma_trains_only_hit_op_sel_swizzles():
         if int(row["bystander"]) != 3:
             assert int(row["bystanders_bad"]) == 0, row
         else:
+            # (asserted as well: see test_back_to_back_mfma_chains_leave_the_neighbours_alone)
+            assert int(row["bystanders_bad"]) > 0, ("MFMA trains no longer disturb op_sel-swizzled packed arithmetic of the SIMD's other "
+                                                    "waves: revisit hazard 4 in DESIGN.md section 4", row)
             print("\nop_sel-swizzled v_pk_add_f32 beside trains of three-blocks: %s wrong values" % row["bystanders_bad"])
 
 

@@ -20,10 +20,11 @@ FIELDS = ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "p
 
 
 def table(lib):
-    import test_code_layout as T
+    import test_code_layout as T0
+    T = T0.V                                        # (the build's verifier: w-ofdm-optimization_amd/csrc/verify_code_layout.py)
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for co in T._code_objects(lib, tmp):
+        for co in T.code_objects(lib, tmp):
             notes = subprocess.run([os.path.join(T.LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
                                    check=True).stdout
             for blk in notes.split("- .agpr_count:")[1:]:

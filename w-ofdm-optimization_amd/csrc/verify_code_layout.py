@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Build step: static checks of the device code of a just-linked libwofdm_hip.so (no GPU needed).
+
+    python3 verify_code_layout.py ../libwofdm_hip.so [--report]
+
+`make` runs it behind the link and fails the build on any violation, so that a library built with another
+compiler cannot ship without its guards.  What it checks, in the disassembly of every
+gfx950 code object of the library:
+
+ 1. hazard 1 -- kernels WITH op_sel-swizzled packed arithmetic (every layout but 10 ... 15): each run of MFMAs is
+    six long, back to back, inside ONE 64-byte instruction-cache line;
+ 2. hazard 4 -- kernels of layouts 10 ... 15 (MFMAs as compiler builtins among the vector instructions) contain NO
+    v_pk_* instruction with an op_sel source swizzle;
+ 3. no MFMA has its destination on top of one of its own A / B operands (the gfx950 f16 MFMAs carry no
+    early-clobber constraint in ROCm 7.2);
+ 4. no vector-ALU instruction WRITES an A / B operand register within 12 wait states behind its MFMA
+    (documented software-managed wait states of these instructions; nothing interlocks);
+ 5. no vector-ALU instruction writes an MFMA source fewer than MIN_WRITE_TO_MFMA wait states in front of the
+    MFMA (cdna_hip_programming.md 5.7 item 2: `s_nop 1` = two states for an operand written inside inline asm;
+    the compiler keeps them for the instructions it knows);
+ 6. no kernel of the library contains a flat_* instruction (LDS words are ds_read / ds_write).
+
+tests/test_code_layout.py runs the same scan.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get("WOFDM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+MIN_WRITE_TO_MFMA = 2          # wait states between a vector-ALU write of a register and an MFMA that reads it
+WAR_STATES = 12                # wait states behind an MFMA in which none of its A / B operand registers may be written
+MDFT_LAYOUTS = (10, 11, 12, 13, 14, 15)
+
+
+def tools_present():
+    return os.path.exists(os.path.join(LLVM, "llvm-objdump")) and shutil.which("objcopy") is not None
+
+
+def code_objects(lib, tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    for i, p in enumerate(starts):
+        end = starts[i + 1] if i + 1 < len(starts) else len(data)
+        b = os.path.join(tmp, "b%d.bin" % i)
+        open(b, "wb").write(data[p:end])
+        co = os.path.join(tmp, "b%d.co" % i)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=" + TARGET,
+                        "--input=" + b, "--output=" + co], check=True)
+        yield co
+
+
+def _vregs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _valu_dest(ins):
+    """vector registers a vector-ALU instruction (not an MFMA, not a compare) writes"""
+    if not ins.startswith("v_") or ins.startswith(("v_mfma", "v_cmp_", "v_cmpx_", "v_readlane", "v_readfirstlane")) or " " not in ins:
+        return set()
+    return _vregs(ins.split(None, 1)[1].split(",")[0].strip())
+
+
+def _states(ins):
+    """wait states an instruction takes up in front of a later one"""
+    m = re.match(r"s_nop (\d+)", ins)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def scan(co):
+    """-> dict with per-function chain runs, flat / swizzle counts and the lists of violations"""
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    res = {"chains": [], "flat": {}, "swz": {}, "overlap": [], "war": [], "raw": [], "min_write_to_mfma": {}}
+    fn, run, pending, recent = None, [], [], []
+    for line in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            fn, run, pending, recent = m.group(1), [], [], []
+            res["flat"][fn] = 0
+            res["swz"][fn] = 0
+            continue
+        m = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+        if not m or fn is None:
+            continue
+        addr = int(m.group(1), 16)
+        ins = line.split("//")[0].strip()
+        if ins.startswith("flat_"):
+            res["flat"][fn] += 1
+        if re.match(r"v_pk_\w+ .*op_sel:\[", ins):
+            res["swz"][fn] += 1
+        is_mfma = ins.startswith("v_mfma")
+        # 4: writes behind an MFMA (cycles as the hardware counts them: an MFMA holds the issue for 8, a vector instruction 4)
+        wr = _valu_dest(ins)
+        for pend in list(pending):
+            if wr & pend["src"]:
+                res["war"].append((fn[:90], pend["text"][:70], ins[:60], pend["cyc"]))
+                pending.remove(pend)
+                continue
+            mn = re.match(r"s_nop (\d+)", ins)
+            pend["cyc"] += (int(mn.group(1)) + 1) if mn else (8 if is_mfma else (4 if ins.startswith("v_") else 1))
+            if pend["cyc"] >= WAR_STATES or ins.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")):
+                pending.remove(pend)
+        if is_mfma:
+            ops = re.findall(r"v\[\d+:\d+\]", ins)
+            srcs = set()
+            for t in ops[1:]:
+                srcs |= _vregs(t)
+            # 5: wait states since the last vector-ALU write of one of the sources
+            dist = 0
+            for prev_wr, prev_states, prev_ins in reversed(recent):
+                if prev_wr & srcs:
+                    key = min(dist, 9)
+                    res["min_write_to_mfma"][key] = res["min_write_to_mfma"].get(key, 0) + 1
+                    if dist < MIN_WRITE_TO_MFMA:
+                        res["raw"].append((fn[:90], prev_ins[:60], ins[:70], dist))
+                    break
+                dist += prev_states
+                if dist >= 8:
+                    break
+            run.append(addr)
+            if len(ops) >= 3:
+                pending.append({"src": _vregs(ops[1]) | _vregs(ops[2]), "cyc": 0, "text": ins})
+                if _vregs(ops[0]) & (_vregs(ops[1]) | _vregs(ops[2])):
+                    res["overlap"].append((fn[:90], ins[:90]))
+        else:
+            if len(run) > 1:
+                res["chains"].append((fn, run[0], run[-1] + 8, len(run)))
+            run = []
+        if ins.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier", "s_setpc")):
+            recent = []
+        else:
+            recent.append((wr, _states(ins), ins))
+            if len(recent) > 12:
+                recent.pop(0)
+    return res
+
+
+def is_mdft(fn):
+    """kernel of a layout with its transforms on the matrix pipe (third template argument of wofdm_frames_kernel)"""
+    m = re.search(r"wofdm_frames_kernelILi\d+ELi\dELi(\d+)E", fn)
+    return bool(m) and int(m.group(1)) in MDFT_LAYOUTS
+
+
+def verify(lib):
+    """-> (list of violation strings, summary dict)"""
+    bad, summ = [], {"kernels": 0, "chains": 0, "mdft_kernels": 0, "kernels_with_swizzles": 0, "write_to_mfma_states": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in code_objects(lib, tmp):
+            r = scan(co)
+            for k, v in r["min_write_to_mfma"].items():
+                summ["write_to_mfma_states"][k] = summ["write_to_mfma_states"].get(k, 0) + v
+            for x in r["overlap"]:
+                bad.append("MFMA destination on top of its own operand: %s: %s" % x)
+            for x in r["war"]:
+                bad.append("operand register written %d cycles behind its MFMA: %s: %s | %s" % (x[3], x[0], x[1], x[2]))
+            for x in r["raw"]:
+                bad.append("MFMA source written %d wait state(s) in front of it (need %d): %s: %s | %s"
+                           % (x[3], MIN_WRITE_TO_MFMA, x[0], x[1], x[2]))
+            for fn, a, b, n in r["chains"]:
+                if is_mdft(fn):
+                    continue
+                summ["chains"] += 1
+                if n != 6:
+                    bad.append("MFMA run of %d (not 6) at %#x in %s" % (n, a, fn[:90]))
+                elif a // 64 != (b - 1) // 64:
+                    bad.append("MFMA chain at %#x crosses a 64-byte line in %s" % (a, fn[:90]))
+            for fn, n in r["flat"].items():
+                summ["kernels"] += "wofdm_frames_kernel" in fn
+                if n:
+                    bad.append("%d flat_* instruction(s) in %s" % (n, fn[:90]))
+            for fn, n in r["swz"].items():
+                if is_mdft(fn):
+                    summ["mdft_kernels"] += 1
+                    if n:
+                        bad.append("%d op_sel-swizzled v_pk_* instruction(s) in the matrix-pipe kernel %s" % (n, fn[:90]))
+                elif "wofdm_frames_kernel" in fn and n:
+                    summ["kernels_with_swizzles"] += 1
+    return bad, summ
+
+
+def main(argv):
+    if len(argv) < 2:
+        print(__doc__)
+        return 2
+    if not tools_present():
+        print("verify_code_layout: llvm-objdump / objcopy not found (WOFDM_LLVM_BIN): cannot verify", file=sys.stderr)
+        return 1
+    bad, summ = verify(argv[1])
+    if "--report" in argv:
+        print(summ)
+    if bad:
+        for b in bad[:20]:
+            print("verify_code_layout: " + b, file=sys.stderr)
+        print("verify_code_layout: %d violation(s) in %s -- the library must not be used" % (len(bad), argv[1]), file=sys.stderr)
+        return 1
+    print("verify_code_layout: %d kernels, %d six-MFMA chains in one cache line each, %d matrix-pipe kernels without swizzled "
+          "packed arithmetic: ok" % (summ["kernels"], summ["chains"], summ["mdft_kernels"]))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -68,6 +68,10 @@
 #define WOFDM_TILE_PIPELINE 1
 #endif
 
+// one symbol per wave: the frame's trailing samples ride in the last wave's last tile instead of a tile of their own (phase B)
+#ifndef WOFDM_FOLD_TAIL
+#define WOFDM_FOLD_TAIL 1
+#endif
 // layouts 10, 11: the 256-point transforms as a pipeline over the wave's four symbols (phases A and C)
 #ifndef WOFDM_MDFT_PIPELINE
 #define WOFDM_MDFT_PIPELINE 1
@@ -184,14 +188,17 @@ __device__ __forceinline__ void split_h(v2f y, uint32_t &hi, uint32_t &lo)
     lo = l;
 #endif
 }
-// A matrix operand built from split_h words must not reach its MFMA straight from the last v_fma_mixhi_f16: the MFMA does not see
-// what the vector instruction DIRECTLY in front of it wrote (tools/ubench/mfma_after_mix.hip: every such result wrong, one instruction
-// in between and none is).  The compiler keeps that distance for the instructions it knows -- the mix instructions above are inline
-// asm.  One wait state that both operand halves pass through; tests/test_code_layout.py checks the built library.
+// A matrix operand built from split_h words must not reach its MFMA straight from the vector instruction that wrote it: an operand
+// written inside inline asm needs its wait states spelled out (documented: cdna_hip_programming.md 5.7, item 2; measured:
+// tools/ubench/mfma_after_mix.hip -- every result wrong with no instruction in between, none with one).  The compiler keeps the
+// distance for the instructions it knows; the mix instructions above are inline asm.  Both operand halves pass through this
+// statement; csrc/verify_code_layout.py checks the distance in the built library, as part of the build.
 __device__ __forceinline__ void mma_operand_fence(h8 &hi, h8 &lo)
 {
     // (not volatile: ordered by its operands alone -- as a volatile statement it cost N = 512 one per cent)
-    asm("s_nop 0" : "+v"(hi), "+v"(lo));
+    // Two wait states: the documented figure for an operand written inside inline asm (cdna_hip_programming.md 5.7, item 2:
+    // `s_nop 1`); verify_code_layout.py demands them of the built code.
+    asm("s_nop 1" : "+v"(hi), "+v"(lo));
 }
 __device__ __forceinline__ v2f join_h(uint32_t hi, uint32_t lo)
 {
@@ -771,6 +778,9 @@ template <int NC, bool EXACT>
 __device__ __forceinline__ void mdft_big(const h8 (&xh)[NC], const h8 (&xl)[NC], const mdft_consts &c, const f4 (&t2r)[NC],
                                          const f4 (&t2i)[NC], f4 (&yr)[NC], f4 (&yi)[NC])
 {
+    // (round 4: the sets as a pipeline like the four symbols of layouts 10 / 11 -- second-stage chain of set s, behind it the twiddle
+    // and split of set s + 1, no wait states -- was built and measured: N = 512 -1.5 %, N = 1024 -6 %.  These kernels sit at their
+    // 128-register limit, and the operands of two sets alive at once cost more than the tails; profiles/r04_other_configs.txt)
     f4 tr[NC], ti[NC], dr[NC], di[NC];
 #pragma unroll
     for (int s = 0; s < NC; ++s) {
@@ -2579,6 +2589,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int jl = 8 * ln + 2 * lg;                 // the lane's samples of a tile: jl, jl + 1
         const int jw = s0 * B, LW = SPW * B;
         const bool all_full = !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
+        // The beta + L - 1 trailing samples of the frame only feed the power sums.  One symbol per wave (layouts 8, 12): the last
+        // symbol's last tile is a quarter full (544 = 4.25 x 128, 1056 = 8.25 x 128), and the samples behind the row's end are
+        // exactly the ones the tile's next columns would compute -- their operand words sit in the virtual row behind the last
+        // symbol, their noise pairs continue the row's Philox blocks.  So the LAST wave takes them along in its last tile (round
+        // 4): before, wave 0 ran a tile of its own for them, 31 % / 39 % of its time at N = 512 / 1024, while the other fifteen
+        // waves waited 22 % of theirs at barrier 2 (profiles/r03_stamp_report.txt).  Needs rows of whole 16-byte operand words and an
+        // even number of trailing samples (a lane's two samples of a tile count or do not count together).
+        const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
+        const bool fold_tail = FIR8 && !FIR8M && WOFDM_FOLD_TAIL && tail_total > 0 && (tail_total & 1) == 0 && (B & 3) == 0 && LW - 128 * (NT - 1) + tail_total <= 128
+                               && tail_total <= VT - 12;
+        const bool fold_here = fold_tail && wv == W - 1;
+        const int LWS = LW + (fold_here ? tail_total : 0);      // samples of this wave that count in the power sums
         const v2f zero2 = mk(0.f, 0.f);
         v2f pn2 = zero2, ps2 = zero2;
         // (the round keys are made opaque once per phase here: they may sit in SGPRs for the tile loop,
@@ -2622,9 +2644,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // inside the short virtual row, the wave's last tile inside the frame)
                 int lc = ln;
                 if (trailing) lc = min(ln, 5);
-                else if (G == NT - 1) lc = min(ln, max(0, (B - 128 * (NT - 1) + 7) / 8 - 1));
+                else if (G == NT - 1) lc = min(ln, max(0, (LWS - 128 * (NT - 1) + 7) / 8 - 1));
                 const int q0 = 128 * G + 8 * lc + 4 * lg - 24;
                 const uint32_t *ph0 = rh + q0, *pl0 = rh + loff + q0, *ph1 = ph0 + 16, *pl1 = pl0 + 16;
+                if (G == NT - 1 && !trailing && fold_here) {
+                    // words behind the row's end come from the virtual row S: plane H sits B words behind this row's position
+                    // of the same index (this row's plane L lies between), plane L another VT
+                    if (q0 >= B) { ph0 += B; pl0 += VT; }
+                    if (q0 + 16 >= B) { ph1 += B; pl1 += VT; }
+                }
                 if (G == 0) {
                     const bool z = sy == 0;
                     if (q0 < 0) { ph0 = z ? Hp : rh + q0 - B; pl0 = z ? Hp : rh + q0; }
@@ -2632,7 +2660,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
                 o.h0 = ld16(ph0); o.h1 = ld16(ph1); o.l0 = ld16(pl0); o.l1 = ld16(pl1);
                 // (layout 9: a short row -- N < 512 -- can end in ANY tile, and the rows behind it may still hold fp32 data)
-                if ((FIR8M || G == NT - 1) && !trailing) {
+                if ((FIR8M || G == NT - 1) && !trailing && !fold_here) {
                     // The block that holds the symbol's last samples may reach up to 7 samples past
                     // them (B is even, not a multiple of 8).  The Toeplitz entries that meet those are
                     // zero, but the words there are another row's (possibly the next wave's scratch:
@@ -2723,11 +2751,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
             // (a wave holds at least LW_MIN = SPW N samples: the tiles below that are full in every geometry)
-            bool valid = FULLT || jr < LW;
+            bool valid = FULLT || jr < LWS;
             if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
             v2f n0, n1;
             f4 d;
-            if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE) {
+            // (not at N = 1024: that kernel sits at its 128-register limit, two tiles' operand rows alive at once spill, and the
+            // compiler's own order is 1.5 % faster there -- interleaved A/B, profiles/r04_other_configs.txt)
+            if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE && N < 1024) {
                 // The tile as a hand-placed pipeline (round 4).  A wave issues a DEPENDENT vector instruction every 8.3 cycles
                 // at best and an independent one every 4.3 (tools/ubench/valu_dep.hip); the six MFMAs of the chain are dependent
                 // (16 cycles apart), their operand rows take an LDS round trip, and a vector instruction must neither read the
@@ -2842,8 +2872,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         else tiles(std::false_type{});
         STAMPF(12);
         DELAY_AT(5);
-        const int tail_total = NL - S * B;                  // beta+L-1 (MATLAB order) or 0
-        if (tail_total > 0 && wv == 0) {
+        if (tail_total > 0 && wv == 0 && !fold_tail) {
             // the trailing samples of the frame (they only feed the power sums): one more tile, by
             // wave 0, the wave that reaches barrier 2 first; it reads behind the last wave's symbols
             if constexpr (RELAX) {
