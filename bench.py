@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
+    # first frame of the run (per cell): lets a one-rank run cover exactly the frames an N-rank run covered (bit-identical counters)
+    ap.add_argument("--frame-offset", type=int, default=0)
     # rehearsal of the N>1 code path on a one-GPU box: all ranks on cuda:0, gloo collectives
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     a = ap.parse_args()
@@ -125,7 +127,7 @@ def main():
 
     def step(i):
         # rank r simulates frames [(i*world + r)*F, +F) of every cell
-        plan.launch((i * world + rank) * F, F, counts, stream)
+        plan.launch(a.frame_offset + (i * world + rank) * F, F, counts, stream)
         reduce_counts()
 
     def reduce_counts():
@@ -151,7 +153,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record(stream)
-        plan.launch((a.warmup + i) * world * F + rank * F, F, counts, stream)
+        plan.launch(a.frame_offset + (a.warmup + i) * world * F + rank * F, F, counts, stream)
         ev[i][1].record(stream)
         # counters are running sums, so reducing inside the loop would multiply-count; the
         # reduce of the sweep's counters happens once, below, inside the timed region
@@ -225,6 +227,7 @@ def main():
                                  "HBM is not the bound: generate mode reads constants and writes counters only "
                                  "(traffic = PMC bytes per launch, null when not measured on these sources)."},
             "ber": ber, "snr_db": SNR_DB.tolist(),
+            "bit_errors": [int(x) for x in host[0, :, 0, 0]], "bits": [int(x) for x in host[0, :, 0, 1]],
         }
         if not a.no_cpu_baseline and world == 1:       # CPU leg: rank 0 at N=1 only
             base, fsamp, ocounts = cpu_baseline(W, st, w_tx, w_rx, h, seed)
