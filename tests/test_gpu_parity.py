@@ -704,7 +704,7 @@ def test_lost_flag_is_reported(channels):
     import sys
     root = os.path.join(os.path.dirname(__file__), "..")
     lib = os.path.join(root, "tests", "native", "libwofdm_hip_fault.so")
-    assert os.path.exists(lib), "make -C w-ofdm-optimization_amd/csrc builds it"
+    assert os.path.exists(lib), "make -C tests/native builds it"
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)

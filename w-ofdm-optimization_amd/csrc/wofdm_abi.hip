@@ -178,6 +178,13 @@ int configure(wofdm_plan *pl)
     return WOFDM_OK;
 }
 
+// The gate of launch() below: one mutex and one "last launch" event per device for the whole process.  The two synchronous
+// entry points that launch kernels of their own (wofdm_interference, wofdm_tx_psd: kernels WITH swizzled packed arithmetic)
+// hold the mutex from their device synchronisation to the end of their kernels, so that no frame launch of another thread
+// can slip in beside them.
+std::mutex g_gate_mu;
+hipEvent_t g_gate_last[64] = {};
+
 int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, int force_grid,
            hipStream_t stream)
 {
@@ -224,10 +231,13 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     // they hold no such instruction themselves, every other kernel of the library does.  Each launch waits for the
     // previous launch of this process on the device (an event; free when it is the same stream) -- a kernel fills the GPU
     // on its own, so nothing is lost.
+    // (What the library can NOT order is work it does not launch: kernels of the caller's own -- torch, rocBLAS, RCCL -- on other
+    // streams of the device, or another process's.  include/wofdm.h and INTEGRATION.md state the requirement: nothing else runs
+    // on the device while a launch of layouts 10 ... 15 is in flight, or the plan is switched to the VALU transforms -- option
+    // dft_valu, whose kernels issue one cache-line-aligned chain at a time: hazard 1's safe shape.)
     {
-        static std::mutex mu;
-        static hipEvent_t last[64] = {};
-        std::lock_guard<std::mutex> lock(mu);
+        std::lock_guard<std::mutex> lock(g_gate_mu);
+        hipEvent_t *last = g_gate_last;
         const int dev = pl->device & 63;
         if (last[dev]) HIP_TRY(hipStreamWaitEvent(stream, last[dev], 0));
         else HIP_TRY(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
@@ -930,7 +940,9 @@ int wofdm_interference(const wofdm_cfg *cfg, int device, const float *w_tx, cons
             hipMemcpy(d_h, hp.data(), hp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(WOFDM_E_HIP, "upload failed"); break;
         }
-        (void)hipDeviceSynchronize();      // (no frame kernel of this process beside these kernels: see launch())
+        // (no frame kernel of this process beside these kernels: the gate of launch() is held until they have finished)
+        std::lock_guard<std::mutex> gate(g_gate_mu);
+        (void)hipDeviceSynchronize();
         hipError_t e = hipErrorInvalidValue;
         if (g.N == 64) e = wofdm_interf_launch_n64(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
         if (g.N == 128) e = wofdm_interf_launch_n128(jobs, g.P, g.B, g.mu, g.delta, g.gamma, g.kappa, cfg->n_channels, d_wtx, d_wrx, d_h, d_pow, nullptr);
@@ -979,7 +991,9 @@ int wofdm_tx_psd(const wofdm_cfg *cfg, int device, const float *w_tx, const floa
             hipMemset(d_x, 0, (size_t)len * 8) != hipSuccess) {
             rc = fail(WOFDM_E_HIP, "upload failed"); break;
         }
-        (void)hipDeviceSynchronize();      // (no frame kernel of this process beside these kernels: see launch())
+        // (no frame kernel of this process beside these kernels: the gate of launch() is held until they have finished)
+        std::lock_guard<std::mutex> gate(g_gate_mu);
+        (void)hipDeviceSynchronize();
         hipError_t e = hipErrorInvalidValue;
         if (N == 64) e = wofdm_psd_launch_n64(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);
         if (N == 128) e = wofdm_psd_launch_n128(P, cfg->cp, cfg->cs, overlap, no_symbols, d_w, d_X, d_x, len, d_psd, nullptr);

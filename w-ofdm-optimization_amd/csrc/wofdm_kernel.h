@@ -22,7 +22,9 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   sums  float [2][32]      per-wave signal / noise power partials, double-buffered by frame parity
 //   flags int   [64]         [w] = last loop iteration whose phase A wave w has finished,
 //                            [16] = last iteration whose pilot equaliser G is published, [20] = a wave gave up waiting,
-//                            [32 + w] = (Tx-mask variants) last iteration whose masked symbol wave w has written to its row
+//                            [32 + w] = (Tx-mask variants) last iteration whose masked symbol wave w has written to its row,
+//                            [48 + w] = (Tx-mask variants on the matrix pipe, layouts 9 / 15) last iteration whose row wave w has
+//                            turned into its two f16 planes (the successor's first tile reads the row's last samples)
 //   wtx   float [N + CPCS]   Tx window / N      (needs cp + cs <= CPCS_MAX = 128; 64 at N = 1024,
 //                            where the frame buffer leaves no room for more anyway)
 //   wrx   float [N + 64]     Rx window          (needs tail_rx <= 64)

@@ -63,6 +63,36 @@
 #define WOFDM_NOISE_KEEP_TILES 6
 #endif
 
+// Issue priority of a wave by the phase it is in (s_setprio, 0 .. 3; round 4).  The SIMD's arbiter picks by priority, then age.  The
+// tile loop of phase B is one long run of vector instructions (Philox, Box-Muller) that is always ready to issue; every other
+// phase is short bursts of vector work between LDS round trips, MFMA results, flags and the barrier.  At equal priority a wave
+// in such a phase queues behind the dense one for every burst and its chain of latencies stretches; with the tile loop BELOW
+// everything else the bursts go out at once and the tile loop takes the slots that are left -- which is all of them whenever
+// the others wait.  C2: 12.5 -> 11.3 ms (interleaved A/Bs, profiles/r04_prio_ab.txt).  Three levels: the latency-bound parts (bits,
+// labels, overlap-add, power sums and barrier, gain and noise scaling, Rx loads, demapping) 2, the transforms and the Tx write 1, the
+// tile loop 0 (the transforms at 0 as well: 12.2 ms; at 2: no better than 1; every level above the tile loop alike: +0.8 %).
+#ifndef WOFDM_PRIO_A
+#define WOFDM_PRIO_A 2
+#endif
+#ifndef WOFDM_PRIO_TILES
+#define WOFDM_PRIO_TILES 0
+#endif
+#ifndef WOFDM_PRIO_B3
+#define WOFDM_PRIO_B3 2
+#endif
+#ifndef WOFDM_PRIO_C
+#define WOFDM_PRIO_C 2
+#endif
+#ifndef WOFDM_PRIO_D
+#define WOFDM_PRIO_D 2
+#endif
+#ifndef WOFDM_PRIO_X                                 /* the transforms and the Tx write (layouts with four symbols per wave) */
+#define WOFDM_PRIO_X 1
+#endif
+#ifndef WOFDM_PRIO_ON
+#define WOFDM_PRIO_ON 1
+#endif
+#define WAVE_PRIO(x) do { if (WOFDM_PRIO_ON) __builtin_amdgcn_s_setprio(x); } while (0)
 // layouts 10 ... 15, generate mode: the FIR tile as a hand-placed pipeline (MFMAs between the Philox rounds; see phase B)
 #ifndef WOFDM_TILE_PIPELINE
 #define WOFDM_TILE_PIPELINE 1
@@ -1370,6 +1400,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #endif
     for (; n_items != 0; --n_items) {
         STAMP(7);                                   // loop control, cell changes
+        WAVE_PRIO(WOFDM_PRIO_A);
         // the 32-bit per-lane and per-wave error sums are flushed every 2^14 frames at the latest (a wave
         // counts at most 6144 bit errors per frame)
         if (cell != cur_cell || nfr == (1u << 14)) {
@@ -1973,6 +2004,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPF(9);
+        WAVE_PRIO(WOFDM_PRIO_X);
         if constexpr (MDFT && WOFDM_MDFT_PIPELINE) {
             // The transform as a pipeline over the wave's four symbols (round 4): the sixteen MFMAs of stage 1 are issued at once,
             // then every group is "the six MFMAs of symbol u's second stage, and BEHIND them the twiddle and the f16 split of symbol
@@ -2434,6 +2466,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         DELAY_AT(2);
         STAMP(0);
+        WAVE_PRIO(WOFDM_PRIO_B3);
         if constexpr (RELAXF) {
             // ---- "barrier" 1: publish "my symbols are written"; phase B waits for the
             // predecessor wave only (its last L-1 samples and its fall tail)
@@ -2868,8 +2901,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         };
         DELAY_AT(4);
         STAMPF(11);
+        WAVE_PRIO(WOFDM_PRIO_TILES);
         if (all_full) tiles(std::true_type{});
         else tiles(std::false_type{});
+        WAVE_PRIO(WOFDM_PRIO_B3);
         STAMPF(12);
         DELAY_AT(5);
         if (tail_total > 0 && wv == 0 && !fold_tail) {
@@ -3079,6 +3114,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         STAMP(2);
         __syncthreads();                                                     // ---- barrier 2
         STAMP(3);
+        WAVE_PRIO(WOFDM_PRIO_C);
         DELAY_AT(7);
 
         // ------------------------------------------------------------ C: noise scale, Rx, FFT
@@ -3374,6 +3410,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         wave_sync();
         STAMPC(14);
+        WAVE_PRIO(WOFDM_PRIO_X);
         // the pilot is symbol slot 0 of wave 0, four subcarriers per lane; G = X0 / Y0 (X0 as the table's small integers:
         // the demapper's levels are scaled to match) goes out as one 16-byte row of real and one of imaginary parts
         auto pilot_mdft = [&]() {
@@ -3470,6 +3507,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         } else if constexpr (QW) fft_qw<-1>(v, row(usq), tw, llq);
         else fft_wave<N, -1, SPW>(v, fbw, B, tw, lane);     // v = Y[n]
         STAMPC(15);
+        WAVE_PRIO(WOFDM_PRIO_C);
 
         if constexpr (MDFT) {
             if (DUMP && p.dump.Y) {
@@ -3553,12 +3591,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         }
         DELAY_AT(8);
         STAMP(4);
+        WAVE_PRIO(WOFDM_PRIO_C);
         if constexpr (RELAXF) {
             if (wv != 0) wait_flag(&flags[16], iter, &flags[20]);                        // ---- "barrier" 3
         } else {
             __syncthreads();                                                 // ---- barrier 3
         }
         STAMP(5);
+        WAVE_PRIO(WOFDM_PRIO_D);
         DELAY_AT(9);
 
         // ------------------------------------------------------------ D: equalise, demap, count

@@ -118,8 +118,9 @@ class Plan:
         _lib.check(self.lib.wofdm_plan_set_tx_mask(self._h_plan, m.ctypes.data))
 
     def set_option(self, name, value):
-        """Diagnostic kernel choice (``wofdm_plan_set_option``): ``fir_valu`` 0/1, ``max_spw`` 0/1/2/4,
-        ``txmask_direct`` 0/1.  Same results, other kernels of the family (A/B measurements, tests)."""
+        """Kernel choice (``wofdm_plan_set_option``): ``fir_valu`` 0/1, ``dft_valu`` 0/1 (the transforms on the vector pipe:
+        the kernels for a GPU that is shared with other work, include/wofdm.h), ``max_spw`` 0/1/2/4, ``txmask_direct`` 0/1.
+        Same results, other kernels of the family (A/B measurements, tests)."""
         _lib.check(self.lib.wofdm_plan_set_option(self._h_plan, _lib.OPTIONS[name], int(value)))
 
     def new_counts(self):
