@@ -70,7 +70,8 @@
 // everything else the bursts go out at once and the tile loop takes the slots that are left -- which is all of them whenever
 // the others wait.  C2: 12.5 -> 11.3 ms (interleaved A/Bs, profiles/r04_prio_ab.txt).  Three levels: the latency-bound parts (bits,
 // labels, overlap-add, power sums and barrier, gain and noise scaling, Rx loads, demapping) 2, the transforms and the Tx write 1, the
-// tile loop 0 (the transforms at 0 as well: 12.2 ms; at 2: no better than 1; every level above the tile loop alike: +0.8 %).
+// tile loop 0 (the transforms at 0 as well: 12.2 ms; at 2: no better than 1; every level above the tile loop alike: +0.8 %).  The
+// layouts with one symbol per wave keep their transforms at the upper level: at the middle one N = 512 / 1024 lose 4 % / 8 %.
 #ifndef WOFDM_PRIO_A
 #define WOFDM_PRIO_A 2
 #endif
