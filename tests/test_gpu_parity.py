@@ -60,7 +60,7 @@ def _expected_layout(st, n_fft, S):
             return 4
         if 4 * B <= 64 * 20:
             return 5
-    if n_fft >= 512 and B >= n_fft and B % 2 == 0 and B <= 128 * (9 if n_fft == 1024 else 5):
+    if n_fft >= 512 and B >= n_fft and B <= 128 * (9 if n_fft == 1024 else 5):      # (every stride, odd ones since round 4)
         return 12
     return 2 if (n_fft <= 256 and S % 2 == 0 and 2 * B <= 64 * (2 * (n_fft // 64) + 2)) else 1
 
@@ -286,6 +286,42 @@ def test_even_strides_that_are_not_multiples_of_four(channels, system, n_fft, cp
     for stage in ("tx", "rx", "Y"):
         a, b = np.asarray(gd[stage]).ravel(), np.asarray(od[stage]).ravel()
         assert np.abs(a[:b.size] - b).max() / np.abs(b).max() < 2e-5, stage
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k", [("CPW", 512, 32, 4), ("wrx", 512, 22, 2), ("wrx", 1024, 22, 6), ("CPW", 1024, 10, 4)])
+@pytest.mark.parametrize("S", [16, 7])
+def test_odd_strides_with_one_symbol_per_wave(channels, system, n_fft, cp, k, S):
+    """wrx / CPW / CPwrx have odd strides at every even CP the reference sweeps (delta = 10; matlab/window_optimization.m:39-47).  With
+    one symbol per wave the rows of the odd symbols then start on an odd sample of the frame: their noise pairs take the second half
+    of one Philox block and the first half of the next, the row's last pair holds ONE sample of the row, and the rows sit at 8- and
+    4-byte alignments in LDS.  Since round 4 layout 12 takes them (layout 1 before): counters against the oracle on the same
+    streams, and one frame stage by stage -- an odd symbol's noise, the FIR, the received rows, the transform."""
+    st = W.make_structure(system, n_fft, cp)
+    assert st.stride % 2 == 1
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.array([8.0 + 3 * (k - 2), 20.0 + 3 * (k - 2)], np.float32)
+    h = channels[5:7].astype(np.complex64)
+    seed, off, F = 37, 3, 6
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True)
+    want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        assert plan.kernel_id() == (12, 0)
+        got = plan.run(off, F)
+        again = plan.run(off, F)
+        gc, gd = plan.dump_frame(1, 4)
+    assert np.array_equal(got, again)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    assert got[..., 0].max() > 20
+    assert np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)).max() <= 2, (got[..., 0], want[..., 0])
+    lab, noise = O.gen_labels(osys, seed, 1, 4), O.gen_noise(osys, seed, 1, 4)
+    oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h[1].astype(np.complex128), float(snrs[0]), lab, noise, dump=True)
+    assert _rel(gd["unit_noise"], noise) < 1e-5
+    for stage in ("tx", "conv", "rx", "Y"):
+        a, b = np.asarray(gd[stage]).ravel(), np.asarray(od[stage]).ravel()
+        nn = min(a.size, b.size) if stage == "conv" else b.size
+        assert np.abs(a[:nn] - b[:nn]).max() / np.abs(b).max() < 2e-5, stage
+    assert np.array_equal(gc, oc) or np.abs(gc.astype(np.int64) - oc.astype(np.int64)).max() <= 1
 
 
 @pytest.mark.parametrize("S", [2, 5, 7, 12])

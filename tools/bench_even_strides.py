@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): strides of 2 mod 4 in the one-symbol-per-wave matrix-pipe layouts (12, 15) against layout 1 (plan option fir_valu),
-which ran them before fir_load cut the straddling operand row word by word.   python tools/bench_even_strides.py"""
+"""Developer tool (GPU box): strides of 2 mod 4, and odd strides, in the one-symbol-per-wave matrix-pipe layouts (12, 15) against layout 1
+(plan option fir_valu), which ran them before round 3 / round 4.   python tools/bench_even_strides.py"""
 import os
 import sys
 
@@ -13,7 +13,9 @@ from wofdm_amd import channel_mask as CM  # noqa: E402
 
 ch = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "channels_vehA.npz"))["h"]
 snr = np.arange(-5.0, 51.0, 5.0).astype(np.float32)
-for system, n, cp, k, F, masked in (("wtx", 256, 30, 4, 20000, True), ("WOLA", 512, 30, 4, 10000, False), ("WOLA", 1024, 30, 6, 5000, False)):
+for system, n, cp, k, F, masked in (("wtx", 256, 30, 4, 20000, True), ("WOLA", 512, 30, 4, 10000, False), ("WOLA", 1024, 30, 6, 5000, False),
+                                    # odd strides (wrx / CPW / CPwrx: delta = 10): layout 12 since round 4
+                                    ("CPW", 512, 32, 4, 10000, False), ("CPW", 1024, 32, 6, 5000, False), ("CPW", 256, 32, 4, 20000, True)):
     st = W.make_structure(system, n, cp)
     cfg = W.make_cfg(st, k, 16, 21, 1, snr.size, 1, seed=3)
     for opts in ({}, {"fir_valu": 1}):

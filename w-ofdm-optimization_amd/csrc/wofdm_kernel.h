@@ -114,6 +114,9 @@ static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw =
 static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12 || spw == 15; }
 static inline int wofdm_firm_tiles(int spw) { return spw == 14 ? 11 : ((spw == 7 || spw == 11 || spw == 13) ? 10 : 9); }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
+#ifndef WOFDM_ODD_STRIDES
+#define WOFDM_ODD_STRIDES 1   // odd strides on the matrix pipe with one symbol per wave (layout 12); 0: layout 1 as before round 4
+#endif
 #define WOFDM_FIR8_VT 48      // words per plane of layout 8's virtual row behind the last symbol
 #define WOFDM_FIRM_PRE 24     // zero samples in front of the frame in the f16 planes (taps - 1 <= 24, 16-byte rows)
 static inline int wofdm_rb(int n_fft, int spw = 1)
@@ -148,9 +151,10 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
         if (4 * B <= 64 * wofdm_rb(n_fft, 4)) return 4;
         if (4 * B <= 64 * wofdm_rb(n_fft, 5)) return 5;       // 288 < B <= 320: 20 outputs per lane
     }
-    // one symbol per wave, matrix-pipe FIR: a lane's two samples of a tile are one Philox block and one 16-byte store: even strides
-    // (a 16-byte operand row that straddles the end of a symbol -- B = 2 mod 4 -- is cut word by word, fir_load)
-    if (firm && plain && n_fft >= 512 && B % 2 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
+    // one symbol per wave, matrix-pipe FIR: every stride (a 16-byte operand row that straddles the end of a symbol is cut word by
+    // word, fir_load; with an odd stride the rows of the odd symbols start on an odd sample of the frame: their noise pairs take
+    // two Philox blocks, their last pair holds one sample -- round 4; the LDS takes 16-byte accesses at any 4-byte alignment)
+    if (firm && plain && n_fft >= 512 && (B % 2 == 0 || (mdft && WOFDM_ODD_STRIDES)) && B <= 128 * wofdm_fir8_tiles(n_fft)) return mdft ? 12 : 8;
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
@@ -166,6 +170,11 @@ static inline size_t wofdm_noise_scratch_len(int n_fft, int spw)
     return n_fft >= WOFDM_NOISE_SCRATCH_MIN_N ? (size_t)16 * 64 * wofdm_rb(n_fft, spw) : 0;
 }
 
+// words per plane between the LDS rows of two symbols, one symbol per wave: the stride itself in the Tx-mask layouts (9, 15: the row
+// holds the masked symbol as fp32 first), rounded up to whole 16-byte operand rows in layouts 8 / 12 -- every row and both of its
+// planes then start on 16 bytes whatever the stride (round 4: strides of 2 mod 4 ran on 8-byte-aligned planes before, odd ones not
+// at all)
+static inline int wofdm_row_stride(int spw, int B) { return (spw == 8 || spw == 12) ? ((B + 3) & ~3) : B; }
 // float2 elements of the frame buffer.  Matrix-pipe layouts: the same bytes hold two planes of
 // packed-f16 words (hi and lo halves of every sample), each `len` words long: 24 zeros, the frame,
 // and zeros up to the end of the tile that covers the trailing samples behind the last wave.
@@ -173,7 +182,7 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
     if (wofdm_is_small(spw))
         return (WOFDM_FIRM_PRE + (S - wofdm_nsym(spw, N)) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
-    if (wofdm_is_fir8(spw)) return (8 + 2 * S * B + 2 * WOFDM_FIR8_VT) / 2;
+    if (wofdm_is_fir8(spw)) return (8 + 2 * S * wofdm_row_stride(spw, B) + 2 * WOFDM_FIR8_VT) / 2;
     if (wofdm_is_firm(spw))
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;

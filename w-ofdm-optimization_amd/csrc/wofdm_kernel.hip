@@ -1536,11 +1536,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         {
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], mu = gq[WOFDM_G_MU], rho = gq[WOFDM_G_RHO];
+        // one symbol per wave with the FIR on the matrix pipe (layouts 8, 12): the LDS rows are BR >= B words per plane apart, BR a
+        // multiple of 4, so that every row and both of its planes start on 16 bytes whatever the stride (wofdm_row_stride)
+        const int BR = (FIR8 && !FIR8M) ? ((B + 3) & ~3) : B;
+        (void)BR;
         const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
         const int TS = gq[WOFDM_G_BETA];           // row length of the fall-tail buffer
         TAILS();
         // this wave's SPW symbol slices of the frame
-        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
+        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * BR * s0) : fbuf + (LT - 1) + s0 * B;
         // private row of B complex floats of the wave's symbol slot u (scratch of the transforms,
         // later the received block)
         auto row = [&](int u) -> v2f * {
@@ -1883,11 +1887,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             } else {
             // Tx write: output element (kc, j) = sample t = lane + 64 (j + 4 kc); real parts in xi, imaginary parts in xr
             const bool lastsym = s == S - 1;
-            uint32_t *hrow = Hp + 8 + 2 * B * s;
-            const int DtH = lastsym ? B : 2 * tail_off + s * TS - B - (8 + 2 * B * s);
-            const int DtL = lastsym ? B + VT : DtH + S * TS;
+            uint32_t *hrow = Hp + 8 + 2 * BR * s;
+            const int DtH = lastsym ? 2 * BR - B : 2 * tail_off + s * TS - B - (8 + 2 * BR * s);
+            const int DtL = lastsym ? 2 * BR - B + VT : DtH + S * TS;
             const bool body_tail = rho < gq[WOFDM_G_BETA];
-            uint32_t *pH = hrow + (lane + mu), *pL = pH + B;
+            uint32_t *pH = hrow + (lane + mu), *pL = pH + BR;
             const float *pW = wtx + (lane + mu);
             auto tx12 = [&](auto body_tail_c) {
 #pragma unroll
@@ -1905,7 +1909,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                             const int i = lane + e + mu;
                             const bool tl = i >= B;
                             hrow[i + (tl ? DtH : 0)] = hi;
-                            hrow[i + (tl ? DtL : B)] = lo;
+                            hrow[i + (tl ? DtL : BR)] = lo;
                         } else {
                             pH[e] = hi;
                             pL[e] = lo;
@@ -1936,7 +1940,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                                     split_h(mk(xi[kc][j] * wtx[i], xr[kc][j] * wtx[i]), hi, lo);
                                     const bool tl = i >= B;
                                     hrow[i + (tl ? DtH : 0)] = hi;
-                                    hrow[i + (tl ? DtL : B)] = lo;
+                                    hrow[i + (tl ? DtL : BR)] = lo;
                                 }
                             }
                     }
@@ -2098,13 +2102,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // one symbol per wave, rows of plane H and plane L side by side; the fall tail goes to the
             // tail planes, the last symbol's into the virtual row behind the frame
             const int s = s0;
-            uint32_t *hrow = Hp + 8 + 2 * B * s;
+            uint32_t *hrow = Hp + 8 + 2 * BR * s;
             const bool lastsym = s == S - 1;
-            const int DtH = lastsym ? B : 2 * tail_off + s * TS - B - (8 + 2 * B * s);
-            const int DtL = lastsym ? B + VT : DtH + S * TS;
+            const int DtH = lastsym ? 2 * BR - B : 2 * tail_off + s * TS - B - (8 + 2 * BR * s);
+            const int DtL = lastsym ? 2 * BR - B + VT : DtH + S * TS;
             const bool body_tail = rho < gq[WOFDM_G_BETA];
             // per-lane bases once, element offsets as instruction immediates (see the quarter-wave form)
-            uint32_t *pH = hrow + (lane + mu), *pL = pH + B;
+            uint32_t *pH = hrow + (lane + mu), *pL = pH + BR;
             const float *pW = wtx + (lane + mu);
             uint32_t *pHp = pH - N, *pLp = pL - N;
             const float *pWp = pW - N;
@@ -2122,7 +2126,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         split_h(x * wtx[i], hi, lo);
                         const bool tl = i >= B;
                         hrow[i + (tl ? DtH : 0)] = hi;
-                        hrow[i + (tl ? DtL : B)] = lo;
+                        hrow[i + (tl ? DtL : BR)] = lo;
                     };
                     if constexpr (decltype(body_tail_c)::value) {
                         put_tail(t + mu);
@@ -2500,6 +2504,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // host in MFMA layout) come from L2; the B operands are 16-byte rows of the f16 planes.
         GEO_PHASE();
         const int S = gq[WOFDM_G_S], B = gq[WOFDM_G_B], beta = gq[WOFDM_G_BETA], NL = gq[WOFDM_G_NL];
+        const int BR = (FIR8 && !FIR8M) ? ((B + 3) & ~3) : B;          // (LDS row stride per plane, see phase A)
+        (void)BR;
         const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
         const int W = S / SPW;
         uint32_t *Lp = Hp + plen;
@@ -2582,12 +2588,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         } else if constexpr (FIR8) {
             // overlap-add of the previous symbol's fall tail (m:253-259), in fp32, re-split
             if (s0 > 0 && lane < beta) {
-                uint32_t *hw = Hp + 8 + 2 * B * s0 + lane;
+                uint32_t *hw = Hp + 8 + 2 * BR * s0 + lane;
                 const int it = (s0 - 1) * beta + lane;
                 uint32_t hi, lo;
-                split_h(join_h(hw[0], hw[B]) + join_h(tH[it], tL[it]), hi, lo);
+                split_h(join_h(hw[0], hw[BR]) + join_h(tH[it], tL[it]), hi, lo);
                 hw[0] = hi;
-                hw[B] = lo;
+                hw[BR] = lo;
             }
         } else {
 #pragma unroll
@@ -2610,8 +2616,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     v2f t;
                     if constexpr (FIR8) {
                         const int sy = min(i / B, S), off = i - sy * B;
-                        const uint32_t *hw = Hp + 8 + 2 * B * sy + off;
-                        t = join_h(hw[0], hw[sy == S ? VT : B]);
+                        const uint32_t *hw = Hp + 8 + 2 * BR * sy + off;
+                        t = join_h(hw[0], hw[sy == S ? VT : BR]);
                     } else {
                         t = join_h(Hp[PRE + i], Lp[PRE + i]);
                     }
@@ -2645,13 +2651,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             if (INJECT) {
                 const float2 *src = p.unit_noise + inj * NL + j;
                 n0 = zero2; n1 = zero2;
-                if (v0 && v1 && ((inj * NL) & 1) == 0) {
+                if (v0 && v1 && ((inj * NL + j) & 1) == 0) {
                     const float4 t = *reinterpret_cast<const float4 *>(src);
                     n0 = mk(t.x, t.y); n1 = mk(t.z, t.w);
                 } else {
                     if (v0) n0 = ldg2(src);
                     if (v1) n1 = ldg2(src + 1);
                 }
+            } else if (j & 1) {
+                // odd strides with one symbol per wave: the rows of the odd symbols start on an odd sample of the frame, and a
+                // lane's two samples of a tile are the SECOND half of one Philox block and the FIRST half of the next (the
+                // streams are keyed by the frame's sample index, not by the layout): two blocks per lane in those rows
+                const philox_out oa = stream_block<false>((uint32_t)(j - 1) >> 1, f_lo, f_hi,
+                                                          (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
+                const philox_out ob = stream_block<false>((uint32_t)(j + 1) >> 1, f_lo, f_hi,
+                                                          (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
+                n0 = box_muller<false>(oa.w[2], oa.w[3]);
+                n1 = box_muller<false>(ob.w[0], ob.w[1]);
             } else {
                 const philox_out o = stream_block<false>((uint32_t)j >> 1, f_lo, f_hi,
                                                          (WOFDM_STREAM_NOISE << 28) | cell, key0, key1);
@@ -2672,8 +2688,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // in front of the row (tile 0 only) are the last ones of the previous symbol's rows, or
                 // the zero words in front of symbol 0.
                 const int sy = trailing ? S : s0;
-                const uint32_t *rh = Hp + 8 + 2 * B * sy;
-                const int loff = sy == S ? VT : B;
+                const uint32_t *rh = Hp + 8 + 2 * BR * sy;
+                const int loff = sy == S ? VT : BR;
                 // (columns without a sample read the last column that has one: the trailing tile stays
                 // inside the short virtual row, the wave's last tile inside the frame)
                 int lc = ln;
@@ -2684,13 +2700,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (G == NT - 1 && !trailing && fold_here) {
                     // words behind the row's end come from the virtual row S: plane H sits B words behind this row's position
                     // of the same index (this row's plane L lies between), plane L another VT
-                    if (q0 >= B) { ph0 += B; pl0 += VT; }
-                    if (q0 + 16 >= B) { ph1 += B; pl1 += VT; }
+                    if (q0 >= B) { ph0 += 2 * BR - B; pl0 += BR - B + VT; }
+                    if (q0 + 16 >= B) { ph1 += 2 * BR - B; pl1 += BR - B + VT; }
                 }
                 if (G == 0) {
                     const bool z = sy == 0;
-                    if (q0 < 0) { ph0 = z ? Hp : rh + q0 - B; pl0 = z ? Hp : rh + q0; }
-                    if (q0 + 16 < 0) { ph1 = z ? Hp : rh + q0 + 16 - B; pl1 = z ? Hp : rh + q0 + 16; }
+                    // (the previous row's last samples: its plane H ends B words behind its start, 2 BR words in front of this row)
+                    if (q0 < 0) { ph0 = z ? Hp : rh + q0 + B - 2 * BR; pl0 = z ? Hp : rh + q0 + B - BR; }
+                    if (q0 + 16 < 0) { ph1 = z ? Hp : rh + q0 + 16 + B - 2 * BR; pl1 = z ? Hp : rh + q0 + 16 + B - BR; }
                 }
                 o.h0 = ld16(ph0); o.h1 = ld16(ph1); o.l0 = ld16(pl0); o.l1 = ld16(pl1);
                 // (layout 9: a short row -- N < 512 -- can end in ANY tile, and the rows behind it may still hold fp32 data)
@@ -2775,8 +2792,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             nscr = reinterpret_cast<f4 *>(p.noise_scratch) + ((size_t)blockIdx.x * 16 + wv) * (NT * 64) + lane;
         // (two instantiations of the tile loop: with every lane of every tile in use -- C2 -- the
         // validity selects are not even emitted)
-        auto tiles = [&](auto full_c) {
+        auto tiles = [&](auto full_c, auto odd_c) {
         constexpr bool FULLT = decltype(full_c)::value;
+        // (ODDB: an odd stride with one symbol per wave -- its own instantiation, so that the even strides carry none of it)
+        constexpr bool ODDB = decltype(odd_c)::value;
         // (N = 1024 is at its 128-VGPR limit: no operand prefetch there, the rows are requested per tile)
         constexpr bool PREFETCH = true;
         bops bq;
@@ -2787,11 +2806,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // (a wave holds at least LW_MIN = SPW N samples: the tiles below that are full in every geometry)
             bool valid = FULLT || jr < LWS;
             if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
+            // (odd strides: the wave's last pair holds ONE sample of its row -- the second one is the next row's first)
+            bool valid1 = valid;
+            if constexpr (ODDB) valid1 = valid && (jr + 1 < LWS || ((LW_MIN > 0) && 128 * (G + 1) <= LW_MIN));
             v2f n0, n1;
             f4 d;
             // (not at N = 1024: that kernel sits at its 128-register limit, two tiles' operand rows alive at once spill, and the
             // compiler's own order is 1.5 % faster there -- interleaved A/B, profiles/r04_other_configs.txt)
-            if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE && N < 1024) {
+            if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE && N < 1024 && !ODDB) {
                 // The tile as a hand-placed pipeline (round 4).  A wave issues a DEPENDENT vector instruction every 8.3 cycles
                 // at best and an independent one every 4.3 (tools/ubench/valu_dep.hip); the six MFMAs of the chain are dependent
                 // (16 cycles apart), their operand rows take an LDS round trip, and a vector instruction must neither read the
@@ -2859,7 +2881,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             if constexpr (PREFETCH) {
                 if (G + 1 < NT) bq = fir_load(jw, G + 1, false);
             }
-            noise_pair(jw + jr, valid, valid, n0, n1);
+            noise_pair(jw + jr, valid, valid1, n0, n1);
             if constexpr (MPIPE && !INJECT) {
                 // the tile's six MFMAs spread over its noise draw: one MFMA, then four vector instructions (an MFMA holds
                 // the vector issue for half of its 16 cycles; interleaved A/B of 3, 4, 5, 6, 8: all within 1 %, -2.3 %
@@ -2879,8 +2901,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             acc[2 * G] = c0; acc[2 * G + 1] = c1;
             // (selects, not branches: columns behind the wave's samples may hold anything)
-            const v2f a0 = valid ? c0 : zero2, a1 = valid ? c1 : zero2;
-            const v2f m0 = valid ? n0 : zero2, m1 = valid ? n1 : zero2;
+            const v2f a0 = valid ? c0 : zero2, a1 = valid1 ? c1 : zero2;
+            const v2f m0 = valid ? n0 : zero2, m1 = valid1 ? n1 : zero2;
             ps2 = __builtin_elementwise_fma(a0, a0, ps2);
             ps2 = __builtin_elementwise_fma(a1, a1, ps2);
             pn2 = __builtin_elementwise_fma(m0, m0, pn2);
@@ -2890,12 +2912,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 if (p.dump.conv) {
                     float2 *dc = valid ? p.dump.conv + jw + jr : p.dump.sink;
                     dc[0] = make_float2(e0.x, e0.y);
-                    dc[valid ? 1 : 0] = make_float2(e1.x, e1.y);
+                    *(valid1 ? dc + 1 : p.dump.sink) = make_float2(e1.x, e1.y);
                 }
                 if (p.dump.unit_noise) {
                     float2 *dn = valid ? p.dump.unit_noise + jw + jr : p.dump.sink;
                     dn[0] = make_float2(n0.x * nuns, n0.y * nuns);
-                    dn[valid ? 1 : 0] = make_float2(n1.x * nuns, n1.y * nuns);
+                    *(valid1 ? dn + 1 : p.dump.sink) = make_float2(n1.x * nuns, n1.y * nuns);
                 }
             }
         }
@@ -2903,8 +2925,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         DELAY_AT(4);
         STAMPF(11);
         WAVE_PRIO(WOFDM_PRIO_TILES);
-        if (all_full) tiles(std::true_type{});
-        else tiles(std::false_type{});
+        if constexpr (FIR8 && !FIR8M) {
+            if (B & 1) tiles(std::false_type{}, std::true_type{});
+            else if (all_full) tiles(std::true_type{}, std::false_type{});
+            else tiles(std::false_type{}, std::false_type{});
+        } else {
+            if (all_full) tiles(std::true_type{}, std::false_type{});
+            else tiles(std::false_type{}, std::false_type{});
+        }
         WAVE_PRIO(WOFDM_PRIO_B3);
         STAMPF(12);
         DELAY_AT(5);
@@ -3122,9 +3150,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if constexpr (RELAUNDER) asm volatile("" : "+v"(lane));
         {
         const int S = cS, B = cB, delta = cDelta, gam = cGam, kap = 0;
+        const int BR = (FIR8 && !FIR8M) ? ((B + 3) & ~3) : B;          // (LDS row stride per plane, see phase A)
+        (void)BR;
         const int plen = cPlen;
         (void)S;
-        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * B * s0) : fbuf + (LT - 1) + s0 * B;
+        v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * BR * s0) : fbuf + (LT - 1) + s0 * B;
         auto row = [&](int u) -> v2f * {
             if constexpr (FIRQ)
                 return reinterpret_cast<v2f *>(Hp + (u < SPW / 2 ? 0 : plen) + PRE + s0 * B) + (u % (SPW / 2)) * B;
@@ -3156,28 +3186,44 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
             // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
             // one select between the two per-lane bases plus an instruction immediate)
-            auto noise_scale = [&](auto full_c) {
+            auto noise_scale = [&](auto full_c, auto odd_c) {
             constexpr bool FULLC = decltype(full_c)::value;
+            constexpr bool ODDB = decltype(odd_c)::value;        // (odd stride, one symbol per wave: see the tile loop)
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
                 bool valid = FULLC || jr < LW;
                 if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
+                // (odd strides, one symbol per wave: the row's last pair holds one sample of the row; the 16 bytes would reach
+                // into the next wave's row)
+                const bool half = ODDB && jr == LW - 1;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
                 v2f *dst = (FIR8 || jl < (SPW / 2) * B - 128 * G ? rxb : rxb1) + 128 * G;
-                if (!FULLC) dst = valid ? dst : sink;
+                v2f *dst0 = dst;
+                if (!FULLC) dst = (valid && !half) ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
+                if constexpr (ODDB) {
+                    if (128 * G < LW && LW <= 128 * (G + 1)) {                      // (wave-uniform: the tile with the row's end)
+                        if (half) *dst0 = r0;
+                    }
+                }
                 if (DUMP && p.dump.rx) {
                     float2 *dr = valid ? p.dump.rx + s0 * B + jr : p.dump.sink;
                     const v2f e0 = r0 * p.dump_unscale_rx, e1 = r1 * p.dump_unscale_rx;
                     dr[0] = make_float2(e0.x, e0.y);
-                    dr[valid ? 1 : 0] = make_float2(e1.x, e1.y);
+                    *((valid && !half) ? dr + 1 : p.dump.sink) = make_float2(e1.x, e1.y);
                 }
             }
             };
-            if (all_full) noise_scale(std::true_type{});
-            else noise_scale(std::false_type{});
+            if constexpr (FIR8 && !FIR8M) {
+                if (B & 1) noise_scale(std::false_type{}, std::true_type{});
+                else if (all_full) noise_scale(std::true_type{}, std::false_type{});
+                else noise_scale(std::false_type{}, std::false_type{});
+            } else {
+                if (all_full) noise_scale(std::true_type{}, std::false_type{});
+                else noise_scale(std::false_type{}, std::false_type{});
+            }
         } else if constexpr (DUMP) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
