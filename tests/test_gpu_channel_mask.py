@@ -128,7 +128,7 @@ def test_allocation_rejects_bad_input(channels):
 from wofdm_amd import channel_mask as CM  # noqa: E402
 
 MASK_CASES = [("wtx", 256, 32, 4), ("wtx", 256, 30, 4), ("WOLA", 256, 22, 4), ("CPW", 64, 16, 2), ("CPwrx", 128, 20, 6),
-              ("wrx", 512, 32, 4), ("CP", 256, 16, 4), ("CPwtx", 256, 10, 6)]
+              ("wrx", 512, 32, 4), ("CP", 256, 16, 4), ("CPwtx", 256, 10, 6), ("CPW", 256, 32, 4), ("wrx", 256, 22, 6)]
 
 
 @pytest.mark.parametrize("system,n_fft,cp,k", MASK_CASES)

@@ -158,10 +158,12 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
     return (n_fft <= 256 && S % 2 == 0 && 2 * B <= 64 * wofdm_rb(n_fft, 2)) ? 2 : 1;
 }
 
-// layout of the Tx-mask variants: 9 where the matrix-pipe FIR fits (even strides, as above), else 1
+// layout of the Tx-mask variants: 9 where the matrix-pipe FIR fits (B >= n_fft, B within its tiles; every stride since round 4 --
+// the rows of these layouts keep the stride itself as their pitch, so odd strides put planes on 4- and 8-byte boundaries, which
+// the LDS takes at a price: CPW N = 256 masked 2.63e8 symbols/s against 2.85e8 at an even stride, 1.99e8 in layout 1), else 1
 static inline int wofdm_spw_masked(int n_fft, int B, bool firm)
 {
-    return (firm && B >= n_fft && B % 2 == 0 && B <= 128 * wofdm_fir8_tiles(n_fft)) ? 9 : 1;
+    return (firm && B >= n_fft && (B % 2 == 0 || WOFDM_ODD_STRIDES) && B <= 128 * wofdm_fir8_tiles(n_fft)) ? 9 : 1;
 }
 
 // float2 elements of noise scratch per workgroup (0: not used for this DFT length)

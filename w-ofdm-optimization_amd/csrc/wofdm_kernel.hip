@@ -2925,7 +2925,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         DELAY_AT(4);
         STAMPF(11);
         WAVE_PRIO(WOFDM_PRIO_TILES);
-        if constexpr (FIR8 && !FIR8M) {
+        if constexpr (FIR8) {
             if (B & 1) tiles(std::false_type{}, std::true_type{});
             else if (all_full) tiles(std::true_type{}, std::false_type{});
             else tiles(std::false_type{}, std::false_type{});
@@ -3216,7 +3216,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 }
             }
             };
-            if constexpr (FIR8 && !FIR8M) {
+            if constexpr (FIR8) {
                 if (B & 1) noise_scale(std::false_type{}, std::true_type{});
                 else if (all_full) noise_scale(std::true_type{}, std::false_type{});
                 else noise_scale(std::false_type{}, std::false_type{});
