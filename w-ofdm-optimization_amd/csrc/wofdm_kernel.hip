@@ -1,18 +1,18 @@
 // wofdm_kernel.hip -- the fused w-OFDM frame kernel for gfx950 (MI355X, CDNA4).
 //
 // One workgroup simulates one frame at a time (persistent over a contiguous run of the
-// cell-major (cell, frame) work items); one 64-lane wavefront owns one, two or four OFDM symbols of
+// cell-major (cell, frame) work items); one 64-lane wavefront owns one, two, four, eight or sixteen OFDM symbols of
 // the frame (layout ids: wofdm_kernel.h):
 //
-//   A  Philox bits -> Gray QAM (registers) -> N-point IFFT (in-register 8/16-point DFT stages, one or two
-//      exchanges through the wave's own slice of the LDS frame buffer) -> CP/CS copy x Tx window written
-//      straight from the last stage, in the matrix-pipe layouts split into two packed-f16 words per sample;
-//      the beta-sample fall tail goes to a side buffer
+//   A  Philox bits -> Gray QAM (registers) -> N-point IFFT (layouts 10 ... 15: both 16-point DFT stages as split-f16 products on the
+//      matrix pipe, registers to registers; the others: in-register 8/16-point DFT stages with one or two exchanges through the
+//      wave's own slice of the LDS frame buffer) -> CP/CS copy x Tx window written straight from the last stage, in the
+//      matrix-pipe layouts split into two packed-f16 words per sample; the beta-sample fall tail goes to a side buffer
 //      (matlab/main_BER_calculation.m:246-252, 358-376, 419-439)
 //   -- "barrier" 1: LDS flag of the predecessor wave --
 //   B  add the previous symbol's fall tail onto the own rise tail (overlap-add, m:253-259),
 //      21-tap complex FIR over the serialised frame (conv, m:260): on the matrix pipe as a block-Toeplitz
-//      product in split f16 with fp32 accumulation (layouts 6, 7, 8: six v_mfma_f32_16x16x32_f16 per 128
+//      product in split f16 with fp32 accumulation (layouts 6 ... 15: six v_mfma_f32_16x16x32_f16 per 128
 //      samples), on the VALU from LDS in the others; Philox/Box-Muller unit noise for the same samples,
 //      per-wave partial signal/noise powers (add_wgn, m:277-294)
 //   -- barrier 2 --
@@ -24,7 +24,8 @@
 //
 // No HBM traffic inside the loop in generate mode (N = 1024 parks its unit noise in an L2-resident
 // scratch row): constants come in once per cell, four 64-bit counters go out once per cell.
-// Bound by fp32 VALU issue and LDS; the matrix pipe carries the FIR only.  Template variants add the
+// Bound by vector issue and by how the waves' latencies interleave ("What bounds the kernel"); in the default
+// layouts the matrix pipe carries the FIR AND both transforms.  Template variants add the
 // subcarrier allocation and the per-symbol spectral Tx mask of main_channel_mask.m (VAR), injected
 // randomness (INJECT) and stage dumps (DUMP).
 #include "wofdm_kernel.h"
@@ -2813,6 +2814,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             f4 d;
             // (not at N = 1024: that kernel sits at its 128-register limit, two tiles' operand rows alive at once spill, and the
             // compiler's own order is 1.5 % faster there -- interleaved A/B, profiles/r04_other_configs.txt)
+            // (odd strides take the compiler's order: the pipeline with both Philox blocks of an odd row between the MFMAs was built
+            // and measured -- CPW N = 512 3.55 against 3.63e8, nothing gained)
             if constexpr (MPIPE && !INJECT && WOFDM_TILE_PIPELINE && N < 1024 && !ODDB) {
                 // The tile as a hand-placed pipeline (round 4).  A wave issues a DEPENDENT vector instruction every 8.3 cycles
                 // at best and an independent one every 4.3 (tools/ubench/valu_dep.hip); the six MFMAs of the chain are dependent
