@@ -60,6 +60,10 @@
 #endif
 
 // N = 1024: tiles whose unit noise stays in registers instead of being parked in the HBM scratch row (see phase B)
+// Received samples stored swizzled against the four-way bank conflicts of the noise-scaling stores (layouts 10 / 11 / 12, phase C)
+#ifndef WOFDM_RX_SWIZZLE
+#define WOFDM_RX_SWIZZLE 1
+#endif
 #ifndef WOFDM_NOISE_KEEP_TILES
 #define WOFDM_NOISE_KEEP_TILES 6
 #endif
@@ -2696,7 +2700,11 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 int lc = ln;
                 if (trailing) lc = min(ln, 5);
                 else if (G == NT - 1) lc = min(ln, max(0, (LWS - 128 * (NT - 1) + 7) / 8 - 1));
+#ifdef WOFDM_PROBE_FIRREAD      // timing probe (results wrong): the operand rows of a quarter 16 bytes apart -- no bank conflicts
+                const int q0 = 128 * G + 4 * lc + 64 * (lg & 1) - 24;
+#else
                 const int q0 = 128 * G + 8 * lc + 4 * lg - 24;
+#endif
                 const uint32_t *ph0 = rh + q0, *pl0 = rh + loff + q0, *ph1 = ph0 + 16, *pl1 = pl0 + 16;
                 if (G == NT - 1 && !trailing && fold_here) {
                     // words behind the row's end come from the virtual row S: plane H sits B words behind this row's position
@@ -3164,6 +3172,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             else
                 return fbw + u * B;
         };
+        // (swizzled rows: where a group of four 16-byte units cannot straddle the end of a chunk or a row -- B a multiple of 4 with
+        // four symbols per wave, of 8 with one -- and, one symbol per wave, a lane's NC consecutive samples are whole units; the
+        // reference's even cyclic prefixes of 0 mod 4 in wtx / WOLA / CPwtx / CPwrx / CP, C2, C4 and C5 among them.  rx_sw = 6 or 0:
+        // the mask of the XOR, so that one code path serves both)
+        constexpr bool RXSWZ = (MDFT || MD8) && WOFDM_RX_SWIZZLE;
+        const int rx_sw = !RXSWZ ? 0 : ((MDFT ? (B & 3) == 0 : ((B & 7) == 0 && (gam & 1) == 0)) ? 6 : 0);
+        auto rx_swz = [&](int x) { return x ^ ((x >> 3) & rx_sw); };      // sample index -> position in the row
+        (void)rx_swz;
         // total powers: ONE LDS round trip -- lane l reads partial sum l & 31 (signal powers of the waves in 0..15, noise
         // powers in 16..31; entries of waves the frame does not have stay zero), rows 0 and 1 of the wave add up
         float Ps, Pn;
@@ -3183,9 +3199,29 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // layouts: samples [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
             const int jl = 8 * (lane & 15) + 2 * (lane >> 4), LW = SPW * B;
             const bool all_full = !DUMP && LW == 128 * NT;
-            v2f *rxb = (FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B)) + jl;
+            // The received samples go into the rows SWIZZLED (round 4, layouts 10 / 11 / 12): lane (ln, lg) holds the 16-byte unit 4 ln + lg
+            // of a tile, and a ds_write_b128 is served in groups of eight consecutive lanes against 32 banks (MI355X_MICROARCH.md, LDS):
+            // eight units 64 bytes apart sit on two 16-byte slots of the 128-byte bank row -- four-way conflicts, 32 LDS cycles per
+            // store where 8 do, all of this phase's conflict cycles, and ON the critical path (a timing probe with conflict-free
+            // store addresses: C2 -8 %, N = 512 -5 %, N = 1024 -7 %, profiles/r04_lds_conflict_probe.txt).  Sample x of a row (or of a
+            // plane's chunk) is kept at x ^ ((x >> 3) & 6): the unit's two low index bits XORed with bits 3..4 of the unit index
+            // (rx_swz).  For the writer that is lg -> lg ^ (ln / 2 % 4), a per-lane constant folded into its two bases (in the
+            // plane-L chunk, which starts 2B samples in, ln - B/4 takes ln's place): the eight lanes of a group hit the eight slots
+            // of a bank row.  The readers undo it in their per-lane bases (below): their elements lie multiples of 64 samples apart,
+            // which leaves bits 3..5 of the index alone.
+            int jlH = jl, jlL = jl;
+            if constexpr (RXSWZ) {
+                const int ln_ = lane & 15;
+                jlH = jl ^ (ln_ & rx_sw);
+                jlL = jl ^ ((ln_ - (B >> 2)) & rx_sw);
+            }
+#ifdef WOFDM_PROBE_RXWRITE      // timing probe (results wrong): the stores of a quarter 16 bytes apart -- no bank conflicts
+            jlH = jlL = 2 * (lane & 15) + 32 * (lane >> 4);
+#endif
+            v2f *rxb0_ = FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B);
+            v2f *rxb = rxb0_ + jlH;
             const int dlt = FIR8 ? 0 : (plen - SPW * B) / 2;
-            v2f *rxb1 = rxb + dlt;                                  // the lane's base in the plane-L chunk (samples from 2B on)
+            v2f *rxb1 = rxb0_ + dlt + jlL;                          // the lane's base in the plane-L chunk (samples from 2B on)
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
             // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
             // one select between the two per-lane bases plus an instruction immediate)
@@ -3346,12 +3382,28 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // Rx window / fold into INPUT element order (NC consecutive samples per element j), split, transform
             const int lb = lane & 15, lg = lane >> 4;
             const v2f *fy = row(0) + gam;
+            // (swizzled rows: the lane's NC consecutive samples are one or two 16-byte units, each at its own per-lane base; the
+            // elements j lie N / 4 = 128 or 256 samples apart, which leaves the XOR term as it is -- instruction offsets as before)
+            const v2f *fyc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                fyc[c] = fy;
+                if constexpr (RXSWZ) {
+                    const int x = gam + (N / 16) * lg + NC * lb + (c & ~1);
+                    fyc[c] = row(0) + rx_swz(x) - ((N / 16) * lg + NC * lb + (c & ~1));
+                }
+            }
             v2f vin[NC][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n0 = (N / 16) * (lg + 4 * j) + NC * lb;
+#ifdef WOFDM_PROBE_RXREAD       // timing probe (results wrong): 16-byte reads of a quarter 16 bytes apart -- no bank conflicts
 #pragma unroll
-                for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fy[n0 + c], wrx[n0 + c]);
+                for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fy[(N / 16) * (lg + 4 * j) + 2 * lb + (c & 1) + 32 * (c >> 1)], wrx[n0 + c]);
+#else
+#pragma unroll
+                for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fyc[c][n0 + c], wrx[n0 + c]);
+#endif
             }
             if (delta > 0) {
                 // (only element 0 of lane group 0 can have a folded partner: tail_rx <= 64 <= N/16)
@@ -3359,7 +3411,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     if (n0 + c < delta) {
-                        vin[c][0] = wfma(fy[n0 + c + N], wrx[n0 + c + N], vin[c][0]);
+                        vin[c][0] = wfma(fyc[c][n0 + c + N], wrx[n0 + c + N], vin[c][0]);
                     }
             }
             wave_sync();
@@ -3420,6 +3472,25 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         {
             (void)kap; (void)h2;
             const int l0 = QW ? llq : lane;                      // the lane's first element of a symbol
+            if constexpr (MDFT && RXSWZ) {
+                // swizzled rows (see the noise-scaling stores above): element r of symbol u is sample x + 64 r of the chunk of its
+                // plane, x = (u % 2) B + gamma + lane; 64 samples on leave the XOR term alone -- one per-lane base per symbol, the
+                // elements (and the folded partner, N samples on) at instruction offsets as before
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const v2f *cb = reinterpret_cast<const v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B);
+                    const v2f *fe = cb + rx_swz((u & 1) * B + gam + lane);
+                    const float *wr = wrx + lane;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][0][r] = fe[64 * r] * wr[64 * r];
+                    if (delta > 0) {
+                        if (lane < delta) {
+                            const float w2 = wr[N];
+                            v[u][0][0] = __builtin_elementwise_fma(mk(w2, w2), fe[N], v[u][0][0]);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < VS; ++u) {
                 const v2f *fy = row(sym_of(u) - s0) + (gam + l0);
@@ -3457,6 +3528,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             }
+            }       // (not swizzled)
         }
         wave_sync();
         STAMPC(14);
