@@ -172,7 +172,8 @@ int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
  * the VALU; 6, 7 = the same with the FIR on the matrix pipe; 9 = one symbol per wave with the FIR on the matrix pipe (Tx-mask
  * variants); 10, 11 = 6, 7 with both 256-point transforms on
  * the matrix pipe as well; 8 = one symbol per wave (N >= 512), FIR on the matrix pipe; 12 = 8 with both transforms on the
- * matrix pipe; 13, 14 = N = 64 / 128, sixteen / eight symbols per wave, FIR and transforms on the matrix pipe; 15 = 9 at N = 256 with
+ * matrix pipe; 13, 14 = N = 64 / 128, sixteen / eight symbols per wave, FIR and transforms on the matrix pipe; 16 = 13 with a run-time
+ * number of symbols per wave and a partly filled last wave (no_symbols not a multiple of 16 / 8, long strides); 15 = 9 at N = 256 with
  * the fast-convolution Tx mask: the symbol's transforms and the mask's two 1024-point transforms on the matrix pipe as well.  Variant: 0 plain, 1 subcarrier allocation, 2 / 3 = Tx mask in direct / fast-
  * convolution form.  (Test and profiling aid; the results do not depend on it beyond fp32 rounding.) */
 int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
@@ -187,7 +188,7 @@ int wofdm_plan_kernel_id(wofdm_plan *plan, int32_t id[2]);
  *                            of fast convolution where that fits; 0 = default
  *   WOFDM_OPT_DFT_VALU       1 = the 256-point IDFT / DFT (dftmtx, main_BER_calculation.m:306, 370) as in-register radix-16
  *                            stages on the VALU (layouts 6, 7) instead of split-f16 products on the matrix pipe (layouts
- *                            10, 11); likewise n_fft = 512, 1024 (8 instead of 12), 64, 128 (2 instead of 13, 14) and the Tx-mask
+ *                            10, 11); likewise n_fft = 512, 1024 (8 instead of 12), 64, 128 (2 instead of 13, 14, 16) and the Tx-mask
  *                            kernel at n_fft = 256 (9 instead of 15); 0 = default */
 #define WOFDM_OPT_FIR_VALU       0
 #define WOFDM_OPT_MAX_SPW        1

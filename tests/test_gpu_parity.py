@@ -50,6 +50,12 @@ def _expected_layout(st, n_fft, S):
             return 13
         if (1024 // n_fft) * B <= 128 * 11:
             return 14
+    if n_fft <= 128 and B >= n_fft:
+        # layout 16: a run-time number of symbols per wave (wofdm_small_spwr): the frame spread evenly over at most four waves
+        for waves in range(1, 5):
+            spwr = (-(-S // waves) + 1) & ~1
+            if spwr <= 1024 // n_fft and spwr * B <= 128 * 10 and (waves - 1) * spwr < S:
+                return 16
     if n_fft == 256 and S % 4 == 0 and B >= n_fft:
         if 4 * B <= 128 * 9:
             return 10
@@ -156,7 +162,7 @@ def test_fir_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("fir_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (6, 7, 8, 10, 11, 12, 13, 14)) == (valu == 0), layout
+            assert (layout in (6, 7, 8, 10, 11, 12, 13, 14, 16)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e = np.abs(gd["conv"] - od["conv"])
         # ... and the FIR alone: against the fp64 convolution of the kernel's OWN transmitted frame (the chain's error
@@ -196,7 +202,7 @@ def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
         with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
             plan.set_option("dft_valu", valu)
             layout = plan.kernel_id()[0]
-            assert (layout in (10, 11, 12, 13, 14)) == (valu == 0), layout
+            assert (layout in (10, 11, 12, 13, 14, 16)) == (valu == 0), layout
             gc, gd = plan.dump_frame(cell, frame, lab, noise.astype(np.complex64))
         e_tx = np.abs(gd["tx"] - od["tx"]) / np.sqrt(np.mean(np.abs(od["tx"]) ** 2))
         # forward transform alone: the oracle's Rx stage (window, fold, shift, DFT) applied in fp64 to the kernel's own rx
@@ -322,6 +328,46 @@ def test_odd_strides_with_one_symbol_per_wave(channels, system, n_fft, cp, k, S)
         nn = min(a.size, b.size) if stage == "conv" else b.size
         assert np.abs(a[:nn] - b[:nn]).max() / np.abs(b).max() < 2e-5, stage
     assert np.array_equal(gc, oc) or np.abs(gc.astype(np.int64) - oc.astype(np.int64)).max() <= 1
+
+
+@pytest.mark.parametrize("system,n_fft,cp,k,S,waves", [
+    ("wtx", 64, 32, 2, 16, 2),       # VERDICT r3's case: 16 x 96 samples are 12 tiles -- two waves of eight symbols
+    ("wtx", 64, 64, 2, 16, 2), ("WOLA", 64, 16, 4, 12, 1), ("wrx", 64, 16, 2, 11, 1), ("wtx", 64, 16, 6, 9, 1), ("CPW", 64, 32, 4, 16, 2),
+    ("CPW", 128, 32, 4, 12, 2), ("WOLA", 128, 32, 6, 5, 1), ("CP", 128, 16, 2, 3, 1), ("WOLA", 128, 32, 4, 9, 2), ("wrx", 128, 56, 2, 16, 3)])
+def test_small_dfts_with_partly_filled_waves(channels, system, n_fft, cp, k, S, waves):
+    """N = 64, 128 where layouts 13 / 14 do not fit -- symbolsPerTx not a multiple of 16 / 8, strides beyond their ten / eleven tiles
+    (N = 64 at CP 32) -- ran the round-1 layout 2 until round 4.  Layout 16 is layout 13 with a run-time number of symbols per wave and a
+    partly filled last wave: counters against the oracle on the same streams, repeatability, and one frame stage by stage (the last
+    symbol's fall tail and the zeros behind the frame sit INSIDE the last wave's rows there)."""
+    st = W.make_structure(system, n_fft, cp)
+    w_tx, w_rx = W.tx_rc_window(st).astype(np.float32), W.rx_rc_window(st).astype(np.float32)
+    snrs = np.array([6.0 + 3 * (k - 2), 18.0 + 3 * (k - 2)], np.float32)
+    h = channels[5:7].astype(np.complex64)
+    seed, off, F = 41, 3, 9
+    cfg = W.make_cfg(st, k, S, 21, 2, 2, 1, seed=seed)
+    osys = _osys(st, k, S, 21, True)
+    want = O.run(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h.astype(np.complex128), snrs.astype(np.float64), seed, off, F)
+    with W.Plan(cfg, w_tx, w_rx, h, snrs) as plan:
+        assert plan.kernel_id() == (16, 0) and plan.info()["waves_per_workgroup"] == waves
+        got = plan.run(off, F)
+        again = plan.run(off, F)
+        gc, gd = plan.dump_frame(1, 4)
+        gc2, gd2 = plan.dump_frame(1, 5)                     # (a second frame through the same rows: nothing of the first is left behind)
+    assert np.array_equal(got, again)
+    assert np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3])
+    assert got[0, 0, 0, 1] == F * (S - 1) * n_fft * k and got[..., 0].max() > 10
+    assert np.abs(got[..., 0].astype(np.int64) - want[..., 0].astype(np.int64)).max() <= 2, (got[..., 0], want[..., 0])
+    assert np.abs(got[..., 2].astype(np.int64) - want[..., 2].astype(np.int64)).max() <= 2, (got[..., 2], want[..., 2])
+    for fr, c_, d_ in ((4, gc, gd), (5, gc2, gd2)):
+        lab, noise = O.gen_labels(osys, seed, 1, fr), O.gen_noise(osys, seed, 1, fr)
+        oc, od = O.frame(osys, w_tx.astype(np.float64), w_rx.astype(np.float64), h[1].astype(np.complex128), float(snrs[0]), lab, noise, dump=True)
+        assert np.array_equal(d_["labels_tx"], lab)
+        assert _rel(d_["unit_noise"], noise) < 1e-5
+        for stage in ("tx", "conv", "rx", "Y"):
+            a, b = np.asarray(d_[stage]).ravel(), np.asarray(od[stage]).ravel()
+            nn = min(a.size, b.size) if stage == "conv" else b.size
+            assert np.abs(a[:nn] - b[:nn]).max() / np.abs(b).max() < 2e-5, (stage, fr)
+        assert np.abs(c_.astype(np.int64) - oc.astype(np.int64)).max() <= 1, (c_, oc)
 
 
 @pytest.mark.parametrize("S", [2, 5, 7, 12])

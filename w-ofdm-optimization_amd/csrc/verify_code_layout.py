@@ -33,7 +33,7 @@ LLVM = os.environ.get("WOFDM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 MIN_WRITE_TO_MFMA = 2          # wait states between a vector-ALU write of a register and an MFMA that reads it
 WAR_STATES = 12                # wait states behind an MFMA in which none of its A / B operand registers may be written
-MDFT_LAYOUTS = (10, 11, 12, 13, 14, 15)
+MDFT_LAYOUTS = (10, 11, 12, 13, 14, 15, 16)
 
 
 def tools_present():

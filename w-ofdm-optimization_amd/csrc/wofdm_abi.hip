@@ -163,10 +163,12 @@ int configure(wofdm_plan *pl)
     }
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * g.S / wofdm_nsym(spw, g.N), lds));
+        &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * wofdm_waves(spw, g.N, g.S, g.B), lds));
     if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
     const int fbuf = wofdm_fbuf_len(g.N, g.T, spw, g.S, g.B);
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
+    const int spwr = wofdm_spwr(spw, g.N, g.S, g.B);
+    HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_SPWR, &spwr, sizeof(int), hipMemcpyHostToDevice));
     for (int m = 0; m < 4; ++m) pl->fn[m] = fn[m];
     pl->var = var; pl->spw = spw; pl->occ = occ; pl->base.lds_bytes = lds;
     // scale of the on-air samples inside the kernel (wofdm_kparams): 1/N of the IDFT, times the
@@ -242,7 +244,7 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
         if (last[dev]) HIP_TRY(hipStreamWaitEvent(stream, last[dev], 0));
         else HIP_TRY(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid),
-                                dim3(64u * (unsigned)(pl->g.S / wofdm_nsym(pl->spw, pl->g.N))), args, kp.lds_bytes, stream));
+                                dim3(64u * (unsigned)wofdm_waves(pl->spw, pl->g.N, pl->g.S, pl->g.B)), args, kp.lds_bytes, stream));
         HIP_TRY(hipEventRecord(last[dev], stream));
     }
     return WOFDM_OK;
@@ -460,6 +462,7 @@ int wofdm_plan_create(wofdm_plan **out, const wofdm_cfg *cfg, int device, const 
     geo[WOFDM_G_NL] = g.NL; geo[WOFDM_G_NSNR] = cfg->n_snr; geo[WOFDM_G_NCH] = cfg->n_channels;
     geo[WOFDM_G_FBUF] = 0;                       // set by configure()
     geo[WOFDM_G_NACT] = g.N;
+    geo[WOFDM_G_SPWR] = 0;                       // set by configure()
     PLAN_TRY(hipMalloc(&pl->d_geo, sizeof geo));
     PLAN_TRY(hipMemcpy(pl->d_geo, geo, sizeof geo, hipMemcpyHostToDevice));
 
@@ -687,7 +690,7 @@ int wofdm_plan_status(wofdm_plan *pl)
 int wofdm_plan_info(wofdm_plan *pl, int32_t info[5])
 {
     if (!pl || !info) return fail(WOFDM_E_INVALID, "NULL argument");
-    info[0] = pl->g.S / wofdm_nsym(pl->spw, pl->g.N);
+    info[0] = wofdm_waves(pl->spw, pl->g.N, pl->g.S, pl->g.B);
     info[1] = (int32_t)pl->base.lds_bytes;
     info[2] = pl->cus * pl->occ;
     info[3] = pl->occ;

@@ -48,6 +48,7 @@ template <int N> struct wofdm_lds {
 enum { WOFDM_G_S, WOFDM_G_MU, WOFDM_G_RHO, WOFDM_G_BETA, WOFDM_G_DELTA, WOFDM_G_GAMMA, WOFDM_G_KAPPA,
        WOFDM_G_L, WOFDM_G_P, WOFDM_G_B, WOFDM_G_T, WOFDM_G_NL, WOFDM_G_NSNR, WOFDM_G_NCH, WOFDM_G_FBUF,
        WOFDM_G_NACT,      // loaded subcarriers (WOFDM_VAR_ALLOC)
+       WOFDM_G_SPWR,      // layout 16: symbols a wave takes (wofdm_small_spwr; the other layouts hold theirs at compile time)
        WOFDM_G_COUNT };
 
 struct wofdm_kparams {
@@ -104,16 +105,22 @@ static inline int wofdm_kslot(int k) { return k == 6 ? 8 : k; }
 // 12 = 8 with both transforms on the matrix pipe as well (N = 512, 1024: 16 . 16 . N/256, the last stage in registers)
 // 13 / 14 = N = 64, 128 with the FIR and both transforms on the matrix pipe: 16 / 8 symbols per wave (one MFMA stage over the stride-N/16
 // index, the radix-N/16 stage in registers), 10 / 11 FIR tiles per wave
-static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11 || spw == 13 || spw == 14; }
-static inline bool wofdm_is_small(int spw) { return spw == 13 || spw == 14; }
+// 16 = 13 with a RUN-TIME number of symbols per wave (even, <= 1024 / N) and a partly filled last wave: the N = 64, 128 geometries
+// layouts 13 / 14 do not take -- S not a multiple of 16 / 8, strides beyond their tiles (N = 64 at CP 32: two waves of eight
+// symbols) -- which ran layout 2 before (round 4)
+static inline bool wofdm_is_mdft(int spw) { return spw == 10 || spw == 11 || spw == 13 || spw == 14 || spw == 16; }
+static inline bool wofdm_is_small(int spw) { return spw == 13 || spw == 14 || spw == 16; }
 // 9 = one symbol per wave, FIR on the matrix pipe, for the Tx-mask variants (any N <= 512): layout 8's frame format; the mask
 // stage works on the rows as fp32, phase B turns them into the f16 planes in place
 // 15 = 9 at N = 256 for the fast-convolution Tx mask with every transform on the matrix pipe: the symbol's own two as in layout 12
 // (one set), the mask's two 1024-point ones as four sets each with no exchange in between (no mask scratch in LDS)
 static inline bool wofdm_is_fir8(int spw) { return spw == 8 || spw == 9 || spw == 12 || spw == 15; }
 static inline bool wofdm_is_firm(int spw) { return (spw >= 6 && spw <= 9) || wofdm_is_mdft(spw) || spw == 12 || spw == 15; }
-static inline int wofdm_firm_tiles(int spw) { return spw == 14 ? 11 : ((spw == 7 || spw == 11 || spw == 13) ? 10 : 9); }
+static inline int wofdm_firm_tiles(int spw) { return spw == 14 ? 11 : ((spw == 7 || spw == 11 || spw == 13 || spw == 16) ? 10 : 9); }
 static constexpr int wofdm_fir8_tiles(int n_fft) { return n_fft >= 1024 ? 9 : (n_fft >= 512 ? 5 : 3); }
+#ifndef WOFDM_SMALL_PARTIAL
+#define WOFDM_SMALL_PARTIAL 1 // layout 16 (N = 64, 128 with a run-time number of symbols per wave); 0: layout 2 there, as before round 4
+#endif
 #ifndef WOFDM_ODD_STRIDES
 #define WOFDM_ODD_STRIDES 1   // odd strides on the matrix pipe with one symbol per wave (layout 12); 0: layout 1 as before round 4
 #endif
@@ -127,8 +134,30 @@ static inline int wofdm_rb(int n_fft, int spw = 1)
 }
 static inline int wofdm_nsym(int spw, int n_fft = 256)
 {
-    if (wofdm_is_small(spw)) return 1024 / n_fft;           // 16 symbols per wave at N = 64, 8 at N = 128
+    if (wofdm_is_small(spw)) return 1024 / n_fft;           // 16 symbols per wave at N = 64, 8 at N = 128 (layout 16: at most)
     return wofdm_is_fir8(spw) ? 1 : ((spw == 5 || wofdm_is_firm(spw)) ? 4 : spw);
+}
+// Layout 16: the symbols a wave takes -- the frame spread evenly over the fewest waves (at most four) whose share, rounded up to
+// an even count (a wave's rows are split between the two f16 planes), fits the 1024 / N symbol slots and the ten tiles of a
+// wave; 0: none fits.  The last wave takes what is left (S - (W - 1) spwr symbols, any count >= 1).
+static inline int wofdm_small_spwr(int n_fft, int S, int B)
+{
+    const int slots = 1024 / n_fft;
+    for (int W = 1; W <= 4; ++W) {
+        const int spwr = ((S + W - 1) / W + 1) & ~1;
+        if (spwr <= slots && spwr * B <= 128 * 10 && (W - 1) * spwr < S) return spwr;
+    }
+    return 0;
+}
+// symbols per wave as the kernel of layout `spw` runs this geometry, and the waves of its workgroup
+static inline int wofdm_spwr(int spw, int n_fft, int S, int B)
+{
+    return spw == 16 ? wofdm_small_spwr(n_fft, S, B) : wofdm_nsym(spw, n_fft);
+}
+static inline int wofdm_waves(int spw, int n_fft, int S, int B)
+{
+    const int r = wofdm_spwr(spw, n_fft, S, B);
+    return r > 0 ? (S + r - 1) / r : 0;
 }
 // symbols per wave: four at N = 256 without Tx mask (quarter-wave layout, S a multiple of 4,
 // four symbols within the 64 x 18 FIR outputs of a wave), else two where the register budget allows
@@ -145,6 +174,7 @@ static inline int wofdm_spw(int n_fft, int S, int B, bool plain = false, bool fi
         if ((1024 / n_fft) * B <= 128 * wofdm_firm_tiles(13)) return 13;
         if ((1024 / n_fft) * B <= 128 * wofdm_firm_tiles(14)) return 14;
     }
+    if (WOFDM_MAX_SPW >= 4 && WOFDM_SMALL_PARTIAL && plain && mdft && firm && n_fft <= 128 && wofdm_small_spwr(n_fft, S, B) > 0) return 16;
     if (WOFDM_MAX_SPW >= 4 && plain && n_fft == 256 && S % 4 == 0) {
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(6)) return mdft ? 10 : 6;
         if (firm && 4 * B <= 128 * wofdm_firm_tiles(7)) return mdft ? 11 : 7;
@@ -182,8 +212,9 @@ static inline int wofdm_row_stride(int spw, int B) { return (spw == 8 || spw == 
 // and zeros up to the end of the tile that covers the trailing samples behind the last wave.
 static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
 {
+    // (behind the last wave's first sample: its tiles and one more of zeros; layout 16: the last wave starts at (W - 1) spwr B)
     if (wofdm_is_small(spw))
-        return (WOFDM_FIRM_PRE + (S - wofdm_nsym(spw, N)) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
+        return (WOFDM_FIRM_PRE + (wofdm_waves(spw, N, S, B) - 1) * wofdm_spwr(spw, N, S, B) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     if (wofdm_is_fir8(spw)) return (8 + 2 * S * wofdm_row_stride(spw, B) + 2 * WOFDM_FIR8_VT) / 2;
     if (wofdm_is_firm(spw))
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;

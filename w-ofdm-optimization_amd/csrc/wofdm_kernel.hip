@@ -1138,7 +1138,7 @@ struct maskfft_geo {
 // (LAY = layout id = symbols per wave, except 5 = four symbols with 20 instead of 18 outputs per
 // lane, for strides of up to 320 samples)
 template <int N, int LAY> struct fir_geo {
-    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12 || LAY == 15) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 14 ? 22 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 20 : 18))
+    static constexpr int RB = (LAY == 8 || LAY == 9 || LAY == 12 || LAY == 15) ? 2 * wofdm_fir8_tiles(N) : LAY >= 6 ? (LAY == 14 ? 22 : ((LAY == 7 || LAY == 11 || LAY == 13 || LAY == 16) ? 20 : 18))
                               : (LAY == 1 ? N / 64 + 1 : (LAY == 5 ? 20 : LAY * (N / 64) + 2));
     static constexpr bool EVEN = (LAY != 1) && (RB % 2 == 0);
     static constexpr int NBK = EVEN ? RB / 2 : RB / 2 + 1;      // Philox blocks per lane
@@ -1182,7 +1182,13 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool MDM = LAY == 15;
     constexpr bool MDX = MD8 || MDM;                       // one symbol per wave, transforms by mdft_big
     // layouts 13, 14: N = 64 / 128, sixteen / eight symbols per wave, ONE matrix stage + the radix-N/16 stage in registers (radix4_elems)
-    constexpr bool MDS = LAY == 13 || LAY == 14;
+    // layout 16: 13 with a RUN-TIME number of symbols per wave, SPWR <= SPW (even; gm[WOFDM_G_SPWR], wofdm_small_spwr), and a partly
+    // filled last wave: wave w takes the symbols w SPWR ..., its rows are SPWR B words per plane, and the symbol slots it does not
+    // fill (slot u = 4 group + lane group >= nreal) compute along but store nothing -- what lies behind a wave's samples is the next
+    // wave's, or the zeros behind the frame.  For the geometries layouts 13 / 14 do not take: S not a multiple of 16 / 8, strides
+    // beyond their tiles (N = 64 at CP 32: two waves of eight symbols); they ran layout 2 before (round 4).
+    constexpr bool PART = LAY == 16;
+    constexpr bool MDS = LAY == 13 || LAY == 14 || PART;
     constexpr int SC = N / 16, SCS = MDS ? SC / 4 : 1, SGR = 4 / SCS;      // elements per lane and symbol, sets per group, groups
     constexpr bool MPIPE = MDFT || MD8 || MDS || MDM;                    // kernels without op_sel-swizzled packed arithmetic (see mma33)
     constexpr int NC = MD8 ? N / 256 : 1;                  // (layout 15: one set)
@@ -1191,7 +1197,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     constexpr bool FIR8M = LAY == 9 || LAY == 15;
     constexpr bool FIRQ = LAY == 6 || LAY == 7 || MDFT || MDS, FIR8 = LAY == 8 || MD8 || FIR8M, FIRM = FIRQ || FIR8;
     constexpr int SPW = MDS ? 1024 / N : (FIR8 ? 1 : (LAY >= 5 ? 4 : LAY));     // symbols per wave
-    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 14 ? 11 : ((LAY == 7 || LAY == 11 || LAY == 13) ? 10 : 9)), PRE = WOFDM_FIRM_PRE;
+    constexpr int NT = FIR8 ? wofdm_fir8_tiles(N) : (LAY == 14 ? 11 : ((LAY == 7 || LAY == 11 || LAY == 13 || PART) ? 10 : 9)), PRE = WOFDM_FIRM_PRE;
     constexpr int VT = WOFDM_FIR8_VT;
     static_assert(!FIR8 || FIR8M || (N >= 512 && VAR <= 1), "layout 8 is built for N >= 512 without Tx mask");
     static_assert(!FIR8M || VAR >= 2, "layout 9 is the Tx-mask variants' matrix-pipe FIR layout");
@@ -1215,7 +1221,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     // workgroups, three of them per CU at up to 168 VGPRs
     constexpr bool QW = SPW == 4 && !MDFT && !MDS;
     static_assert(!(QW || MDFT) || (N == 256 && VAR <= 1), "the four-symbol layouts are built for N = 256 without Tx mask");
-    static_assert(!MDS || ((N == 64 || N == 128) && VAR <= 1), "layouts 13 / 14 are built for N = 64, 128, without Tx mask");
+    static_assert(!MDS || ((N == 64 || N == 128) && VAR <= 1), "layouts 13 / 14 / 16 are built for N = 64, 128, without Tx mask");
     constexpr int VS = QW ? 1 : (MDS ? 1 : SPW), VB = QW ? 4 : BPL;      // register arrays [VS][VB][4]
     constexpr int RB = fir_geo<N, LAY>::RB, NBK = fir_geo<N, LAY>::NBK;
     constexpr bool EVEN = fir_geo<N, LAY>::EVEN;
@@ -1237,7 +1243,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
     const int tid = threadIdx.x, lane0 = tid & 63;
     // the wave index is wave-uniform: keep it (and everything derived from it) in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s0 = wv * SPW;                       // first of this wave's SPW symbols
+    // first of this wave's symbols (layout 16: SPWR of them, a run-time count; SPWR2 = half of it, the rows per f16 plane)
+    const int SPWR = PART ? __builtin_amdgcn_readfirstlane(gm[WOFDM_G_SPWR]) : SPW, SPWR2 = SPWR >> 1;
+    (void)SPWR2;
+    const int s0 = wv * SPWR;
     int lane = lane0;
     // The structure lengths live in a small device array (gm[WOFDM_G_*]) that every phase
     // re-reads by scalar loads through a laundered pointer (GEO_PHASE): held in registers for
@@ -1553,16 +1562,21 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         // private row of B complex floats of the wave's symbol slot u (scratch of the transforms,
         // later the received block)
         auto row = [&](int u) -> v2f * {
-            if constexpr (FIRQ)
+            if constexpr (PART)
+                return reinterpret_cast<v2f *>(Hp + (u < SPWR2 ? 0 : plen) + PRE + s0 * B) + (u < SPWR2 ? u : u - SPWR2) * B;
+            else if constexpr (FIRQ)
                 return reinterpret_cast<v2f *>(Hp + (u < SPW / 2 ? 0 : plen) + PRE + s0 * B) + (u % (SPW / 2)) * B;
             else
                 return fbw + u * B;
         };
+        // (layout 16: the symbol slots this wave fills)
+        const int nreal = PART ? min(SPWR, S - s0) : SPW;
+        (void)nreal;
         mdft_early dce;
         if constexpr (MDFT || MDX) dce = mdft_request();
         if (!INJECT) {
             // Philox words of the wave's symbols, staged in the (still unused) frame slices
-            if (lane < SPW * bps) {
+            if (lane < SPW * bps && (!PART || lane / bps < nreal)) {
                 const int ub = lane / bps, blk = lane % bps;
                 const philox_out o = stream_block((uint32_t)((s0 + ub) * bps + blk), f_lo, f_hi,
                                                   (WOFDM_STREAM_BITS << 28) | cell, seed_lo, seed_hi);
@@ -1595,7 +1609,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
-                const uint32_t *bw = reinterpret_cast<const uint32_t *>(row(sr));
+                // (layout 16: an unfilled slot reads slot 0's words and transmits nothing)
+                const bool son = !PART || sr < nreal;
+                const int srr = son ? sr : 0;
+                const uint32_t *bw = reinterpret_cast<const uint32_t *>(row(srr));
                 li[t] = 0;
                 // byte j of the word: 0x80 when subcarrier SC (g + 4 j) + c is NOT loaded (second part of the table: this layout's
                 // order, one word per set and lane); the flag rides in the label byte down to phase D
@@ -1606,7 +1623,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     const int n = SC * (lg + 4 * j) + c;
                     uint32_t Lb;
                     if (INJECT) {
-                        Lb = p.labels[(inj * S + s0 + sr) * N + n] & lmask;
+                        Lb = p.labels[(inj * S + s0 + srr) * N + n] & lmask;
                     } else {
                         const uint32_t bit = (uint32_t)n * (uint32_t)ks;
                         Lb = (bw[bit >> 5] >> (bit & 31u)) & lmask;
@@ -1616,7 +1633,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     if constexpr (ALLOC) {
                         if ((am >> (8 * j)) & 0x80u) xw[t][j] = 0u;
                     }
-                    if (DUMP) {
+                    if constexpr (PART) {
+                        if (!son) xw[t][j] = 0u;
+                    }
+                    if (DUMP && son) {
                         const hpair hw = __builtin_bit_cast(hpair, xw[t][j]);
                         if (p.dump.labels_tx) p.dump.labels_tx[(s0 + sr) * N + n] = (uint8_t)Lb;
                         if (p.dump.X) p.dump.X[(s0 + sr) * N + n] = make_float2((float)hw.y * qscale, (float)hw.x * qscale);
@@ -1630,8 +1650,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
+                if (!PART || sr < nreal) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lbytes[sr * N + SC * (lg + 4 * j) + c] = (uint8_t)(li[t] >> (8 * j));
+                    for (int j = 0; j < 4; ++j) lbytes[sr * N + SC * (lg + 4 * j) + c] = (uint8_t)(li[t] >> (8 * j));
+                }
             }
             wave_sync();
 #pragma unroll
@@ -1645,6 +1667,15 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 asm volatile("" : "+v"(labo[t]));
             }
             wave_sync();
+            if constexpr (PART) {
+                // The partly filled last wave: its rows -- this phase's scratch, and the received samples of the frame before, kept as
+                // complex floats across BOTH planes of the chunk -- reach into the plane positions behind its symbols, which the
+                // FIR reads as the frame's end: the last symbol's fall tail (written below) and zeros.  Put the zeros back.
+                if (nreal < SPWR) {
+                    const int z1 = PRE + (s0 + SPWR) * B;
+                    for (int i = PRE + (s0 + nreal) * B + TS + lane; i < z1; i += 64) { Hp[i] = 0u; Hp[plen + i] = 0u; }
+                }
+            }
             STAMPF(9);
             f4 tr[4], ti[4];
 #pragma unroll
@@ -1668,6 +1699,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const bool lastsym = s == S - 1;
                 const int DtH = lastsym ? 0 : 2 * tail_off + s * TS - (PRE + (s + 1) * B);
                 const int DtL = lastsym ? 0 : DtH + S * TS - plen;
+                if (PART && 4 * (t / SCS) + lg >= nreal) continue;       // (an unfilled slot stores nothing)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kc = SC == 4 ? e : 2 * e + (t % SCS);
@@ -2512,7 +2544,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         const int BR = (FIR8 && !FIR8M) ? ((B + 3) & ~3) : B;          // (LDS row stride per plane, see phase A)
         (void)BR;
         const int plen = FIRQ ? gq[WOFDM_G_FBUF] : 0;
-        const int W = S / SPW;
+        const int W = PART ? (S + SPWR - 1) / SPWR : S / SPW;
+        const int nreal = PART ? min(SPWR, S - s0) : SPW;        // (layout 16: the symbol slots this wave fills)
         uint32_t *Lp = Hp + plen;
         TAILS();
         const int ln = lane & 15, lg = lane >> 4;       // MFMA column / row group of the lane
@@ -2604,7 +2637,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int sb = 0; sb < SPW; sb += 4) {              // (sixteen lanes per symbol, four symbols at a time)
                 const int s = s0 + sb + lg;
-                if (s > 0 && ln < beta) {
+                if (s > 0 && ln < beta && (!PART || sb + lg < nreal)) {
                     const int idx = PRE + s * B + ln, it = (s - 1) * beta + ln;
                     uint32_t hi, lo;
                     split_h(join_h(Hp[idx], Lp[idx]) + join_h(tH[it], tL[it]), hi, lo);
@@ -2632,8 +2665,8 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             __syncthreads();
         }
         const int jl = 8 * ln + 2 * lg;                 // the lane's samples of a tile: jl, jl + 1
-        const int jw = s0 * B, LW = SPW * B;
-        const bool all_full = !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
+        const int jw = s0 * B, LW = nreal * B;
+        const bool all_full = !PART && !DUMP && LW == 128 * NT;  // every lane of every tile owns two samples
         // The beta + L - 1 trailing samples of the frame only feed the power sums.  One symbol per wave (layouts 8, 12): the last
         // symbol's last tile is a quarter full (544 = 4.25 x 128, 1056 = 8.25 x 128), and the samples behind the row's end are
         // exactly the ones the tile's next columns would compute -- their operand words sit in the virtual row behind the last
@@ -2744,9 +2777,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 // plane-H word of x[j - 24] is Hp[PRE + j - 24] = Hp[j]
                 const uint32_t *b = Hp + first + 128 * G + 8 * ln + 4 * lg;
                 o.h0 = ld16(b); o.h1 = ld16(b + 16); o.l0 = ld16(b + plen); o.l1 = ld16(b + plen + 16);
-                if (G == NT - 1 && !trailing && !all_full) {
+                if ((PART || G == NT - 1) && !trailing && !all_full) {
                     // odd strides: the block with the wave's last samples reaches 4 samples into the next
                     // wave's rows, which may still hold that wave's scratch (0 x NaN): zero those words
+                    // (layout 16: a wave's samples can end in any tile, at any stride)
                     const int q0 = 128 * G + 8 * ln + 4 * lg - 24;
                     const h8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (q0 >= LW) { o.h0 = zr; o.l0 = zr; }
@@ -2812,12 +2846,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
         for (int G = 0; G < NT; ++G) {
             const int jr = 128 * G + jl;
+            if constexpr (PART) {
+                // (tiles behind the wave's samples are skipped: two waves of eight symbols at N = 64, CP 32 fill six of ten)
+                if (128 * G >= LWS) {
+                    acc[2 * G] = acc[2 * G + 1] = zero2;
+                    nz[2 * G] = nz[2 * G + 1] = zero2;
+                    continue;
+                }
+            }
             // (a wave holds at least LW_MIN = SPW N samples: the tiles below that are full in every geometry)
             bool valid = FULLT || jr < LWS;
             if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
             // (odd strides: the wave's last pair holds ONE sample of its row -- the second one is the next row's first)
             bool valid1 = valid;
             if constexpr (ODDB) valid1 = valid && (jr + 1 < LWS || ((LW_MIN > 0) && 128 * (G + 1) <= LW_MIN));
+            // (layout 16: an odd number of symbols at an odd stride ends the wave on an odd sample -- the pair's second one is the first
+            // of the frame's trailing samples, which wave 0's trailing tile counts)
+            if constexpr (PART) valid1 = valid && jr + 1 < LWS;
             v2f n0, n1;
             f4 d;
             // (not at N = 1024: that kernel sits at its 128-register limit, two tiles' operand rows alive at once spill, and the
@@ -3167,18 +3212,22 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         (void)S;
         v2f *fbw = FIR8 ? reinterpret_cast<v2f *>(Hp + 8 + 2 * BR * s0) : fbuf + (LT - 1) + s0 * B;
         auto row = [&](int u) -> v2f * {
-            if constexpr (FIRQ)
+            if constexpr (PART)
+                return reinterpret_cast<v2f *>(Hp + (u < SPWR2 ? 0 : plen) + PRE + s0 * B) + (u < SPWR2 ? u : u - SPWR2) * B;
+            else if constexpr (FIRQ)
                 return reinterpret_cast<v2f *>(Hp + (u < SPW / 2 ? 0 : plen) + PRE + s0 * B) + (u % (SPW / 2)) * B;
             else
                 return fbw + u * B;
         };
+        const int nreal = PART ? min(SPWR, S - s0) : SPW;        // (layout 16: the symbol slots this wave fills)
+        (void)nreal;
         // (swizzled rows: where a group of four 16-byte units cannot straddle the end of a chunk or a row -- B a multiple of 4 with
         // four symbols per wave, of 8 with one -- and, one symbol per wave, a lane's NC consecutive samples are whole units; the
         // reference's even cyclic prefixes of 0 mod 4 in wtx / WOLA / CPwtx / CPwrx / CP, C2, C4 and C5 among them.  rx_sw = 6 or 0:
         // the mask of the XOR, so that one code path serves both)
         constexpr bool RXSWZ = (MDFT || MD8) && WOFDM_RX_SWIZZLE;
         const int rx_sw = !RXSWZ ? 0 : ((MDFT ? (B & 3) == 0 : ((B & 7) == 0 && (gam & 1) == 0)) ? 6 : 0);
-        auto rx_swz = [&](int x) { return x ^ ((x >> 3) & rx_sw); };      // sample index -> position in the row
+        auto rx_swz = [&](int x) { return x ^ ((((x >> 4) & 2) | ((x >> 2) & 4)) & rx_sw); };      // sample index -> position in the row
         (void)rx_swz;
         // total powers: ONE LDS round trip -- lane l reads partial sum l & 31 (signal powers of the waves in 0..15, noise
         // powers in 16..31; entries of waves the frame does not have stay zero), rows 0 and 1 of the wave add up
@@ -3197,30 +3246,33 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         if constexpr (FIRM) {
             // r = c + g n (m:292-293) as two-sample rows into the wave's private rows.  Quarter-wave
             // layouts: samples [0, 2B) of the wave sit in its chunk of plane H, [2B, 4B) in that of plane L
-            const int jl = 8 * (lane & 15) + 2 * (lane >> 4), LW = SPW * B;
-            const bool all_full = !DUMP && LW == 128 * NT;
+            const int jl = 8 * (lane & 15) + 2 * (lane >> 4), LW = nreal * B;
+            const bool all_full = !PART && !DUMP && LW == 128 * NT;
             // The received samples go into the rows SWIZZLED (round 4, layouts 10 / 11 / 12): lane (ln, lg) holds the 16-byte unit 4 ln + lg
             // of a tile, and a ds_write_b128 is served in groups of eight consecutive lanes against 32 banks (MI355X_MICROARCH.md, LDS):
             // eight units 64 bytes apart sit on two 16-byte slots of the 128-byte bank row -- four-way conflicts, 32 LDS cycles per
             // store where 8 do, all of this phase's conflict cycles, and ON the critical path (a timing probe with conflict-free
             // store addresses: C2 -8 %, N = 512 -5 %, N = 1024 -7 %, profiles/r04_lds_conflict_probe.txt).  Sample x of a row (or of a
-            // plane's chunk) is kept at x ^ ((x >> 3) & 6): the unit's two low index bits XORed with bits 3..4 of the unit index
-            // (rx_swz).  For the writer that is lg -> lg ^ (ln / 2 % 4), a per-lane constant folded into its two bases (in the
-            // plane-L chunk, which starts 2B samples in, ln - B/4 takes ln's place): the eight lanes of a group hit the eight slots
-            // of a bank row.  The readers undo it in their per-lane bases (below): their elements lie multiples of 64 samples apart,
-            // which leaves bits 3..5 of the index alone.
+            // plane's chunk) is kept at rx_swz(x): bit 1 of the index XORed with its bit 5, bit 2 with its bit 4 -- the unit's two
+            // low index bits with bits 4 and 3 of the unit index.  For the writer that is lg ^ (bits 2 and 1 of ln, swapped), a
+            // per-lane constant folded into its two bases (in the plane-L chunk, which starts 2B samples in, ln - B/4 takes ln's
+            // place): the eight lanes of a group hit the eight slots of a bank row.  The readers undo it in their per-lane bases
+            // (below): their elements lie multiples of 64 samples apart, which leaves bits 4..5 of the index alone.  (Which bits
+            // go where is chosen for the READERS: with this pairing layout 12's 32-byte-strided ds_read_b128 at N = 1024 -- 2-way
+            // conflicts before -- are conflict-free as well, by the bank rule and lane groups of MI355X_MICROARCH.md; the pairing
+            // bit 1 <-> 4, 2 <-> 5 serves the writer alike and leaves those at 2-way.)
             int jlH = jl, jlL = jl;
             if constexpr (RXSWZ) {
-                const int ln_ = lane & 15;
-                jlH = jl ^ (ln_ & rx_sw);
-                jlL = jl ^ ((ln_ - (B >> 2)) & rx_sw);
+                const int ln_ = lane & 15, lt_ = ln_ - (B >> 2);
+                jlH = jl ^ ((((ln_ >> 1) & 2) | ((ln_ << 1) & 4)) & rx_sw);
+                jlL = jl ^ ((((lt_ >> 1) & 2) | ((lt_ << 1) & 4)) & rx_sw);
             }
 #ifdef WOFDM_PROBE_RXWRITE      // timing probe (results wrong): the stores of a quarter 16 bytes apart -- no bank conflicts
             jlH = jlL = 2 * (lane & 15) + 32 * (lane >> 4);
 #endif
             v2f *rxb0_ = FIR8 ? fbw : reinterpret_cast<v2f *>(Hp + PRE + s0 * B);
             v2f *rxb = rxb0_ + jlH;
-            const int dlt = FIR8 ? 0 : (plen - SPW * B) / 2;
+            const int dlt = FIR8 ? 0 : (plen - SPWR * B) / 2;
             v2f *rxb1 = rxb0_ + dlt + jlL;                          // the lane's base in the plane-L chunk (samples from 2B on)
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
             // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
@@ -3231,6 +3283,9 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
+                if constexpr (PART) {
+                    if (128 * G >= LW) continue;
+                }
                 bool valid = FULLC || jr < LW;
                 if constexpr (LW_MIN > 0) valid = valid || 128 * (G + 1) <= LW_MIN;
                 // (odd strides, one symbol per wave: the row's last pair holds one sample of the row; the 16 bytes would reach
@@ -3238,7 +3293,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const bool half = ODDB && jr == LW - 1;
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
-                v2f *dst = (FIR8 || jl < (SPW / 2) * B - 128 * G ? rxb : rxb1) + 128 * G;
+                v2f *dst = (FIR8 || jl < SPWR2 * B - 128 * G ? rxb : rxb1) + 128 * G;
                 v2f *dst0 = dst;
                 if (!FULLC) dst = (valid && !half) ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
@@ -3313,7 +3368,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sr = 4 * (t / SCS) + (lm >> 2), c = 4 * (t % SCS) + (lm & 3);
-                const v2f *fy = row(sr) + gam;
+                const v2f *fy = row((PART && sr >= nreal) ? 0 : sr) + gam;      // (layout 16: an unfilled slot reads slot 0's row)
                 uint32_t h[4], l[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -3348,6 +3403,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kc = SC == 4 ? e : 2 * e + (t % SCS);
+                        if (PART && 4 * (t / SCS) + lg >= nreal) continue;
                         p.dump.Y[(s0 + 4 * (t / SCS) + lg) * N + lm + 16 * kc] = make_float2(yr[t][e] * us, yi[t][e] * us);
                     }
             }
@@ -3732,6 +3788,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int pp = t % SCS, s = s0 + 4 * (t / SCS) + lg;
+                const bool son = !PART || 4 * (t / SCS) + lg < min(SPWR, gm[WOFDM_G_S] - s0);      // (layout 16: a symbol slot this wave fills)
                 const f4 gr = G4[pp * 16 + lm], gi = G4[(SCS + pp) * 16 + lm];
                 const f4 ehr = yr[t] * gr - yi[t] * gi, ehi = yr[t] * gi + yi[t] * gr;
                 const f4 lvi = ehr * 0.5f + 0.5f * (float)m1, lvq = ehi * -0.5f + 0.5f * (float)m1;
@@ -3740,7 +3797,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 for (int e = 0; e < 4; ++e) {
                     iw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lvi[e], (float)m1), e, iw);
                     qw = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(lvq[e], (float)m1), e, qw);
-                    if (DUMP && p.dump.Xhat && s > 0)
+                    if (DUMP && p.dump.Xhat && s > 0 && son)
                         p.dump.Xhat[(s - 1) * N + lm + 16 * (SC == 4 ? e : 2 * e + pp)] = make_float2(ehr[e] * qscale, ehi[e] * qscale);
                 }
                 constexpr uint32_t GM = K == 2 ? 0u : (K == 4 ? 0x05050505u : 0x1B1B1B1Bu);
@@ -3749,10 +3806,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const uint32_t gw = cw ^ ((cw >> 1) & GM);
                 uint32_t diff = (gw ^ labo[t]) & LM;
                 if constexpr (ALLOC) diff &= ~(((labo[t] >> 7) & 0x01010101u) * 0xFFu);   // bit 7 = not loaded: not counted
-                if (s == 0) diff = 0;                               // the pilot symbol is not counted
+                if (s == 0 || !son) diff = 0;                       // the pilot symbol is not counted (nor an unfilled slot)
                 bit_err += __popc(diff);
                 sym_err += __popc((diff + 0x7F7F7F7Fu) & 0x80808080u);
-                if (DUMP && p.dump.labels_rx && s > 0) {
+                if (DUMP && p.dump.labels_rx && s > 0 && son) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         p.dump.labels_rx[(s - 1) * N + lm + 16 * (SC == 4 ? e : 2 * e + pp)] = (uint8_t)((gw >> (8 * e)) & lmask);
@@ -4189,6 +4246,8 @@ template <int N, int K> wofdm_kernel_fn pick_spw(int spw, int mode, int var)
             return var ? pick_mode<N, K, 13, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 13, WOFDM_VAR_PLAIN>(mode);
         if (spw == 14 && var <= WOFDM_VAR_ALLOC)
             return var ? pick_mode<N, K, 14, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 14, WOFDM_VAR_PLAIN>(mode);
+        if (spw == 16 && var <= WOFDM_VAR_ALLOC)
+            return var ? pick_mode<N, K, 16, WOFDM_VAR_ALLOC>(mode) : pick_mode<N, K, 16, WOFDM_VAR_PLAIN>(mode);
     }
     if (spw == 9) {
         if constexpr (N <= WOFDM_TXMASK_MAX_N) {
