@@ -24,7 +24,8 @@ if n_fft == 256:
 elif n_fft >= 512:
     geos = [("WOLA", 32, 16, {}), ("WOLA", 32, 16, {"fir_valu": 1})]
 else:
-    geos = [("wtx", 16, 16, {}), ("wtx", 16, 9, {})]
+    # (layouts 13 / 14, 16 -- a partly filled wave, and two or three waves at a long stride --, and the VALU layouts 2 and 1)
+    geos = [("wtx", 16, 16, {}), ("wtx", 16, 9, {}), ("wrx", 56, 16, {}), ("wtx", 16, 16, {"dft_valu": 1}), ("wtx", 16, 9, {"dft_valu": 1})]
 total, bad, seen = 0, 0, set()
 for system, cp, S, opts in geos:
     for var in (0, 1, 2, 3):

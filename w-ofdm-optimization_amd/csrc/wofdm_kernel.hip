@@ -3221,12 +3221,18 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
         };
         const int nreal = PART ? min(SPWR, S - s0) : SPW;        // (layout 16: the symbol slots this wave fills)
         (void)nreal;
-        // (swizzled rows: where a group of four 16-byte units cannot straddle the end of a chunk or a row -- B a multiple of 4 with
-        // four symbols per wave, of 8 with one -- and, one symbol per wave, a lane's NC consecutive samples are whole units; the
-        // reference's even cyclic prefixes of 0 mod 4 in wtx / WOLA / CPwtx / CPwrx / CP, C2, C4 and C5 among them.  rx_sw = 6 or 0:
-        // the mask of the XOR, so that one code path serves both)
+        // Swizzled rows of received samples (layouts 10 / 11 / 12; see the noise-scaling stores below).  The swizzle permutes the
+        // four 16-byte units of every aligned group of eight samples of a row (one symbol per wave: B samples) or of a plane's chunk
+        // (four symbols per wave: 2B samples); where the LAST group is incomplete -- B not a multiple of 8 resp. 4: half of the
+        // reference's even cyclic prefixes, and every odd stride -- its samples keep their order (rx_part: writer and readers test
+        // for it in instantiations / branches of their own, the strides of C2, C4 and C5 carry none of it).
+        // (Layout 15 -- the Tx-mask kernel, whose time goes into the mask stage -- measured nothing with it, -1 % at strides with an
+        // incomplete group: it keeps its rows in order.  profiles/r04_rx_swizzle_ab.txt)
         constexpr bool RXSWZ = (MDFT || MD8) && WOFDM_RX_SWIZZLE;
-        const int rx_sw = !RXSWZ ? 0 : ((MDFT ? (B & 3) == 0 : ((B & 7) == 0 && (gam & 1) == 0)) ? 6 : 0);
+        constexpr int rx_sw = RXSWZ ? 6 : 0;
+        const int rx_len = FIR8 ? B : 2 * B, rx_xb = rx_len & ~7;
+        const bool rx_part = RXSWZ && (rx_len & 7) != 0;
+        (void)rx_xb; (void)rx_part;
         auto rx_swz = [&](int x) { return x ^ ((((x >> 4) & 2) | ((x >> 2) & 4)) & rx_sw); };      // sample index -> position in the row
         (void)rx_swz;
         // total powers: ONE LDS round trip -- lane l reads partial sum l & 31 (signal powers of the waves in 0..15, noise
@@ -3255,17 +3261,17 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // store addresses: C2 -8 %, N = 512 -5 %, N = 1024 -7 %, profiles/r04_lds_conflict_probe.txt).  Sample x of a row (or of a
             // plane's chunk) is kept at rx_swz(x): bit 1 of the index XORed with its bit 5, bit 2 with its bit 4 -- the unit's two
             // low index bits with bits 4 and 3 of the unit index.  For the writer that is lg ^ (bits 2 and 1 of ln, swapped), a
-            // per-lane constant folded into its two bases (in the plane-L chunk, which starts 2B samples in, ln - B/4 takes ln's
-            // place): the eight lanes of a group hit the eight slots of a bank row.  The readers undo it in their per-lane bases
+            // per-lane constant folded into its two bases (in the plane-L chunk, which starts 2B samples in, the pair's index there
+            // modulo a tile takes the place of jl): the eight lanes of a group hit the eight slots of a bank row.  The readers undo it in their per-lane bases
             // (below): their elements lie multiples of 64 samples apart, which leaves bits 4..5 of the index alone.  (Which bits
             // go where is chosen for the READERS: with this pairing layout 12's 32-byte-strided ds_read_b128 at N = 1024 -- 2-way
             // conflicts before -- are conflict-free as well, by the bank rule and lane groups of MI355X_MICROARCH.md; the pairing
             // bit 1 <-> 4, 2 <-> 5 serves the writer alike and leaves those at 2-way.)
             int jlH = jl, jlL = jl;
             if constexpr (RXSWZ) {
-                const int ln_ = lane & 15, lt_ = ln_ - (B >> 2);
-                jlH = jl ^ ((((ln_ >> 1) & 2) | ((ln_ << 1) & 4)) & rx_sw);
-                jlL = jl ^ ((((lt_ >> 1) & 2) | ((lt_ << 1) & 4)) & rx_sw);
+                jlH = rx_swz(jl);
+                const int m = (jl - 2 * B) & 127;
+                jlL = jl + (rx_swz(m) - m);
             }
 #ifdef WOFDM_PROBE_RXWRITE      // timing probe (results wrong): the stores of a quarter 16 bytes apart -- no bank conflicts
             jlH = jlL = 2 * (lane & 15) + 32 * (lane >> 4);
@@ -3276,10 +3282,12 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             v2f *rxb1 = rxb0_ + dlt + jlL;                          // the lane's base in the plane-L chunk (samples from 2B on)
             v2f *sink = reinterpret_cast<v2f *>(smem + L::off_flags + 4 * 24);   // 16 idle bytes
             // (two instantiations, as for the tile loop: with every lane of every tile in use -- C2 -- a store's address is
-            // one select between the two per-lane bases plus an instruction immediate)
-            auto noise_scale = [&](auto full_c, auto odd_c) {
+            // one select between the two per-lane bases plus an instruction immediate; a third and fourth where the row's or the
+            // chunk's last group of eight samples is incomplete and keeps its order)
+            auto noise_scale = [&](auto full_c, auto odd_c, auto part_c) {
             constexpr bool FULLC = decltype(full_c)::value;
             constexpr bool ODDB = decltype(odd_c)::value;        // (odd stride, one symbol per wave: see the tile loop)
+            constexpr bool PARTG = decltype(part_c)::value && RXSWZ;
 #pragma unroll
             for (int G = 0; G < NT; ++G) {
                 const int jr = 128 * G + jl;
@@ -3294,6 +3302,10 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                 const v2f r0 = __builtin_elementwise_fma(mk(g, g), nz[2 * G], acc[2 * G]);
                 const v2f r1 = __builtin_elementwise_fma(mk(g, g), nz[2 * G + 1], acc[2 * G + 1]);
                 v2f *dst = (FIR8 || jl < SPWR2 * B - 128 * G ? rxb : rxb1) + 128 * G;
+                if constexpr (PARTG) {
+                    const bool idn = FIR8 ? jr >= rx_xb : ((jr >= rx_xb && jr < rx_len) || jr >= rx_len + rx_xb);
+                    if (idn) dst = rxb0_ + (FIR8 || jr < rx_len ? 0 : dlt) + jr;
+                }
                 v2f *dst0 = dst;
                 if (!FULLC) dst = (valid && !half) ? dst : sink;
                 *reinterpret_cast<f4 *>(dst) = (f4){r0.x, r0.y, r1.x, r1.y};
@@ -3311,12 +3323,14 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             }
             };
             if constexpr (FIR8) {
-                if (B & 1) noise_scale(std::false_type{}, std::true_type{});
-                else if (all_full) noise_scale(std::true_type{}, std::false_type{});
-                else noise_scale(std::false_type{}, std::false_type{});
+                if (B & 1) noise_scale(std::false_type{}, std::true_type{}, std::true_type{});
+                else if (rx_part) noise_scale(std::false_type{}, std::false_type{}, std::true_type{});
+                else if (all_full) noise_scale(std::true_type{}, std::false_type{}, std::false_type{});
+                else noise_scale(std::false_type{}, std::false_type{}, std::false_type{});
             } else {
-                if (all_full) noise_scale(std::true_type{}, std::false_type{});
-                else noise_scale(std::false_type{}, std::false_type{});
+                if (rx_part) noise_scale(std::false_type{}, std::false_type{}, std::true_type{});
+                else if (all_full) noise_scale(std::true_type{}, std::false_type{}, std::false_type{});
+                else noise_scale(std::false_type{}, std::false_type{}, std::false_type{});
             }
         } else if constexpr (DUMP) {
 #pragma unroll
@@ -3438,38 +3452,61 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
             // Rx window / fold into INPUT element order (NC consecutive samples per element j), split, transform
             const int lb = lane & 15, lg = lane >> 4;
             const v2f *fy = row(0) + gam;
-            // (swizzled rows: the lane's NC consecutive samples are one or two 16-byte units, each at its own per-lane base; the
-            // elements j lie N / 4 = 128 or 256 samples apart, which leaves the XOR term as it is -- instruction offsets as before)
-            const v2f *fyc[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                fyc[c] = fy;
-                if constexpr (RXSWZ) {
-                    const int x = gam + (N / 16) * lg + NC * lb + (c & ~1);
-                    fyc[c] = row(0) + rx_swz(x) - ((N / 16) * lg + NC * lb + (c & ~1));
-                }
-            }
             v2f vin[NC][4];
+            // (swizzled rows: the lane's NC consecutive samples are one or two 16-byte units, each at its own per-lane base -- with an
+            // odd gamma, where they straddle units, single samples at NC bases; the elements j lie N / 4 = 128 or 256 samples apart,
+            // which leaves the XOR term as it is: instruction offsets as before)
+            auto rx_load = [&](auto single_c) {
+                constexpr int UM = decltype(single_c)::value ? ~0 : ~1;             // a base per sample, or per pair of samples
+                const v2f *fyc[NC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n0 = (N / 16) * (lg + 4 * j) + NC * lb;
+                for (int c = 0; c < NC; ++c) {
+                    fyc[c] = fy;
+                    if constexpr (RXSWZ) {
+                        const int o = (N / 16) * lg + NC * lb + (c & UM);
+                        fyc[c] = row(0) + rx_swz(gam + o) - o;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n0 = (N / 16) * (lg + 4 * j) + NC * lb;
 #ifdef WOFDM_PROBE_RXREAD       // timing probe (results wrong): 16-byte reads of a quarter 16 bytes apart -- no bank conflicts
 #pragma unroll
-                for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fy[(N / 16) * (lg + 4 * j) + 2 * lb + (c & 1) + 32 * (c >> 1)], wrx[n0 + c]);
+                    for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fy[(N / 16) * (lg + 4 * j) + 2 * lb + (c & 1) + 32 * (c >> 1)], wrx[n0 + c]);
 #else
 #pragma unroll
-                for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fyc[c][n0 + c], wrx[n0 + c]);
+                    for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fyc[c][n0 + c], wrx[n0 + c]);
 #endif
-            }
-            if (delta > 0) {
-                // (only element 0 of lane group 0 can have a folded partner: tail_rx <= 64 <= N/16)
-                const int n0 = (N / 16) * lg + NC * lb;
+                }
+                if (delta > 0) {
+                    // (only element 0 of lane group 0 can have a folded partner: tail_rx <= 64 <= N/16)
+                    const int n0 = (N / 16) * lg + NC * lb;
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (n0 + c < delta) {
-                        vin[c][0] = wfma(fyc[c][n0 + c + N], wrx[n0 + c + N], vin[c][0]);
+                    for (int c = 0; c < NC; ++c)
+                        if (n0 + c < delta) {
+                            vin[c][0] = wfma(fyc[c][n0 + c + N], wrx[n0 + c + N], vin[c][0]);
+                        }
+                }
+                if constexpr (RXSWZ) {
+                    if (rx_part) {
+                        // the row's incomplete last group keeps its order: the elements in it -- element 3 of the last lanes, folded
+                        // partners -- are read once more, where they are
+                        const int n3 = (N / 16) * (lg + 12) + NC * lb;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            if (gam + n3 + c >= rx_xb) vin[c][3] = wmul(fy[n3 + c], wrx[n3 + c]);
+                        if (delta > 0) {
+                            const int n0 = (N / 16) * lg + NC * lb;
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                if (n0 + c < delta && gam + n0 + c + N >= rx_xb)
+                                    vin[c][0] = wfma(fy[n0 + c + N], wrx[n0 + c + N], wmul(fyc[c][n0 + c], wrx[n0 + c]));
+                        }
                     }
-            }
+                }
+            };
+            if (RXSWZ && (NC == 1 || (gam & 1) != 0)) rx_load(std::true_type{});
+            else rx_load(std::false_type{});
             wave_sync();
             STAMPC(14);
             const mdft_consts dc = mdft_load(dce);
@@ -3543,6 +3580,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                         if (lane < delta) {
                             const float w2 = wr[N];
                             v[u][0][0] = __builtin_elementwise_fma(mk(w2, w2), fe[N], v[u][0][0]);
+                        }
+                    }
+                }
+                if (rx_part) {
+                    // the chunk's incomplete last group keeps its order: what the SECOND symbol of a plane's chunk has in it -- element 3
+                    // of its last lanes, folded partners -- is read once more, where it is
+#pragma unroll
+                    for (int u = 1; u < 4; u += 2) {
+                        const v2f *cb = reinterpret_cast<const v2f *>(Hp + (u < 2 ? 0 : plen) + PRE + s0 * B);
+                        const int x0 = B + gam + lane;
+                        const float *wr = wrx + lane;
+                        if (x0 + 192 >= rx_xb) v[u][0][3] = cb[x0 + 192] * wr[192];
+                        if (delta > 0) {
+                            if (lane < delta && x0 + N >= rx_xb) {
+                                const float w2 = wr[N];
+                                v[u][0][0] = __builtin_elementwise_fma(mk(w2, w2), cb[x0 + N], cb[rx_swz(x0)] * wr[0]);
+                            }
                         }
                     }
                 }
