@@ -3474,8 +3474,23 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 #pragma unroll
                     for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fy[(N / 16) * (lg + 4 * j) + 2 * lb + (c & 1) + 32 * (c >> 1)], wrx[n0 + c]);
 #else
+                    if constexpr (!decltype(single_c)::value && NC >= 2) {
+                        // an even gamma: the pairs of samples are whole 16-byte words of the row, asked for as such -- left to the
+                        // compiler, which sees 8-byte alignment only, they were ds_read2_b64 (half the rate of ds_read_b128, served
+                        // against 32 banks in groups of sixteen consecutive lanes: four-way conflicts at this 32-byte lane stride)
+                        f4 wq = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (NC == 4) wq = *reinterpret_cast<const f4 *>(wrx + n0);
+                        else { const v2f w2 = *reinterpret_cast<const v2f *>(wrx + n0); wq.x = w2.x; wq.y = w2.y; }
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fyc[c][n0 + c], wrx[n0 + c]);
+                        for (int c = 0; c < NC; c += 2) {
+                            const f4 t = *reinterpret_cast<const f4 *>(fyc[c] + n0 + c);
+                            vin[c][j] = wmul(mk(t.x, t.y), wq[c]);
+                            vin[c + 1][j] = wmul(mk(t.z, t.w), wq[c + 1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) vin[c][j] = wmul(fyc[c][n0 + c], wrx[n0 + c]);
+                    }
 #endif
                 }
                 if (delta > 0) {
@@ -3505,7 +3520,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
                     }
                 }
             };
-            if (RXSWZ && (NC == 1 || (gam & 1) != 0)) rx_load(std::true_type{});
+            if (NC == 1 || (gam & 1) != 0) rx_load(std::true_type{});
             else rx_load(std::false_type{});
             wave_sync();
             STAMPC(14);
