@@ -4,6 +4,8 @@ bash tools/profile_round.sh r04 > gpurun_out/r04_profile_round.log 2>&1
 tail -4 gpurun_out/r04_profile_round.log
 bash tools/sustained_round.sh r04
 bash tools/other_configs_round.sh r04 > /dev/null 2>&1
+{ echo "# tools/bench_small_partial.py: N = 64 / 128 geometries in layout 16 (round 4: run-time symbols per wave, partly filled last wave) against layout 2 (plan option dft_valu), layouts 13 beside them; 12 SNR points, one channel"
+  timeout -k 10 300 python tools/bench_small_partial.py 2>&1 | grep -v amdgpu.ids; } > gpurun_out/r04_small_partial.txt
 bash tools/stats_bign.sh r04 > gpurun_out/r04_stats_bign.log 2>&1
 bash tools/pmc_bign.sh > gpurun_out/r04_pmc_bign.txt 2>&1
 { echo "# tools/stamp_report.py on the final kernels (-DWOFDM_STAMP build of the N = 256 / 512 / 1024 translation units; layouts 10 / 12 / 12): share of a wave's own"
