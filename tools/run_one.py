@@ -8,7 +8,7 @@ import torch
 import wofdm_amd as W
 system, n, k, nch, nsnr, frames = sys.argv[1], *[int(x) for x in sys.argv[2:7]]
 ch = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "channels_vehA.npz"))["h"]
-st = W.make_structure(system, n, 32)
+st = W.make_structure(system, n, int(os.environ.get("RUN_CP", "32")))
 cfg = W.make_cfg(st, k, 16, 21, nch, nsnr, 1, seed=4)
 snr = (-20 + 3.0 * np.arange(nsnr)).astype(np.float32)
 with W.Plan(cfg, W.tx_rc_window(st), W.rx_rc_window(st), ch[:nch].astype(np.complex64), snr) as plan:

@@ -165,6 +165,8 @@ int configure(wofdm_plan *pl)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &occ, reinterpret_cast<const void *>(fn[WOFDM_MODE_GEN]), 64 * wofdm_waves(spw, g.N, g.S, g.B), lds));
     if (occ < 1) return fail(WOFDM_E_UNSUPPORTED, "kernel does not fit a CU (LDS %u bytes)", lds);
+    // (the LDS goes in units of 5 120 bytes, which the occupancy API does not know: wofdm_lds_workgroups_per_cu)
+    if (occ > wofdm_lds_workgroups_per_cu(lds)) occ = wofdm_lds_workgroups_per_cu(lds);
     const int fbuf = wofdm_fbuf_len(g.N, g.T, spw, g.S, g.B);
     HIP_TRY(hipMemcpy(pl->d_geo + WOFDM_G_FBUF, &fbuf, sizeof(int), hipMemcpyHostToDevice));
     const int spwr = wofdm_spwr(spw, g.N, g.S, g.B);
@@ -194,6 +196,9 @@ int launch(wofdm_plan *pl, int mode, wofdm_kparams &kp, uint64_t total_items, in
     if (!fn) return fail(WOFDM_E_UNSUPPORTED, "no kernel for n_fft=%d", pl->g.N);
     if (total_items == 0) return WOFDM_OK;
     uint64_t grid = (uint64_t)pl->cus * (uint64_t)pl->occ;
+#ifdef WOFDM_DEV_OCC               // developer builds only: workgroups launched per CU (occupancy experiments)
+    grid = (uint64_t)pl->cus * (uint64_t)(WOFDM_DEV_OCC);
+#endif
     if (grid > total_items) grid = total_items;
     if (force_grid > 0) grid = (uint64_t)force_grid;
     const size_t row = wofdm_noise_scratch_len(pl->g.N, pl->spw);

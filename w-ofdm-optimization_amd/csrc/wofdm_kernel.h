@@ -31,10 +31,13 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   lut   float2[64]         QAM constellation by label
 //   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
 //   tail  float2[S][tail_tx] fall tails, behind the frame buffer (then the Tx-mask tables, if any)
-template <int N> struct wofdm_lds {
+// (NOTW: layouts 13 / 14 / 16 -- N = 64, 128 with the transforms on the matrix pipe -- keep no twiddle table: their operand rows come
+// from L2.  Those 512 bytes decide at N = 64 whether a workgroup takes three or four of the LDS's 5 120-byte allocation units --
+// ten or eight workgroups per CU: wofdm_lds_granule)
+template <int N, bool NOTW = false> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
-    static constexpr int TW_BYTES = N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N;
+    static constexpr int TW_BYTES = NOTW ? 0 : (N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N);
     static constexpr int off_g = off_tw + TW_BYTES;
     static constexpr int off_sums = off_g + 8 * N;
     static constexpr int off_flags = off_sums + 4 * 64;
@@ -220,9 +223,19 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
+// The LDS of a CU is handed out in units of 5 120 bytes (160 KiB / 32) on this GPU -- measured, round 4: with 15 808 bytes per
+// one-wave workgroup (four units) a CU holds EIGHT workgroups, not the ten the occupancy API reports, and a grid of ten per CU runs
+// as two rounds (profiles/r04_occ_small.txt); every other kernel's residency agrees with the same unit.  The plan's grid counts
+// workgroups by it.
+#define WOFDM_LDS_GRANULE 5120
+static inline int wofdm_lds_workgroups_per_cu(unsigned lds_bytes)
+{
+    const unsigned units = (lds_bytes + WOFDM_LDS_GRANULE - 1) / WOFDM_LDS_GRANULE;
+    return units ? (int)(160u * 1024u / WOFDM_LDS_GRANULE / units) : 32;
+}
 static inline unsigned wofdm_lds_bytes(int N, int T, int spw, int S, int B)
 {
-    const int fixed = (N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
+    const int fixed = (wofdm_is_small(spw) ? 0 : (N == 256 || N == 512 ? 6 * 64 * 16 : 8 * N)) + 8 * N + 4 * 64 + 4 * 64 + 4 * (N + wofdm_cpcs_max(N)) + 4 * (N + 64) + 8 * 64;
     const int beta = T - S * B;
     // (layout 15, behind the fall tails: 16 bytes of alignment, a row of 344 samples per wave for the mask stage's spill, and 64 spare
     // bytes at the very end -- the target of the mask stage's stores that have no output)

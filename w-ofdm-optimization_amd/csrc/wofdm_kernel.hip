@@ -1258,7 +1258,7 @@ wofdm_frames_kernel(const wofdm_kparams p, const float *__restrict__ g_wtx,
 
     // LDS carve with compile-time offsets (wofdm_lds<N>): only the frame buffer, last, has a
     // run-time length.  Fewer live scalars = fewer SGPR spills in the frame loop.
-    using L = wofdm_lds<N>;
+    using L = wofdm_lds<N, (LAY == 13 || LAY == 14 || LAY == 16)>;
     v2f *tw = reinterpret_cast<v2f *>(smem + L::off_tw);
     v2f *G = reinterpret_cast<v2f *>(smem + L::off_g);
     float *sums = reinterpret_cast<float *>(smem + L::off_sums);
