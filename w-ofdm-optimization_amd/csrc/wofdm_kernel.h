@@ -32,8 +32,8 @@ struct wofdm_kdump {          // device pointers, all may be null
 //   fbuf  float2[fbuf_len]   WOFDM_LT-1 zeros | frame (T) | zeros
 //   tail  float2[S][tail_tx] fall tails, behind the frame buffer (then the Tx-mask tables, if any)
 // (NOTW: layouts 13 / 14 / 16 -- N = 64, 128 with the transforms on the matrix pipe -- keep no twiddle table: their operand rows come
-// from L2.  Those 512 bytes decide at N = 64 whether a workgroup takes three or four of the LDS's 5 120-byte allocation units --
-// ten or eight workgroups per CU: wofdm_lds_granule)
+// from L2.  Those 512 bytes decide at N = 64 whether a workgroup takes twelve or thirteen of the LDS's 128 allocation units --
+// ten or nine workgroups per CU: wofdm_lds_workgroups_per_cu)
 template <int N, bool NOTW = false> struct wofdm_lds {
     static constexpr int TAIL_MAX = 16, CPCS_MAX = N >= 1024 ? 64 : 128, TAILRX_MAX = 64;
     static constexpr int off_tw = 0;
@@ -223,11 +223,12 @@ static inline int wofdm_fbuf_len(int N, int T, int spw, int S = 0, int B = 0)
         return (WOFDM_FIRM_PRE + (S - 4) * B + 128 * (wofdm_firm_tiles(spw) + 1) + 3) / 4 * 4;
     return ((WOFDM_LT - 1) + T + (WOFDM_LT - 1) + wofdm_rb(N, spw) + 8 + 1) / 2 * 2;
 }
-// The LDS of a CU is handed out in units of 5 120 bytes (160 KiB / 32) on this GPU -- measured, round 4: with 15 808 bytes per
-// one-wave workgroup (four units) a CU holds EIGHT workgroups, not the ten the occupancy API reports, and a grid of ten per CU runs
-// as two rounds (profiles/r04_occ_small.txt); every other kernel's residency agrees with the same unit.  The plan's grid counts
-// workgroups by it.
-#define WOFDM_LDS_GRANULE 5120
+// The LDS of a CU is handed out in units of 1 280 bytes (160 KiB / 128) on this GPU -- measured, round 4: with 15 808 bytes per
+// one-wave workgroup (thirteen units) a CU holds NINE workgroups, not the ten the occupancy API reports (158 080 bytes do fit
+// 160 KiB), and a grid of ten per CU ran as two rounds -- nine, then one -- at the rate of five (profiles/r04_occ_small.txt);
+// every other kernel's residency agrees with the same unit (three workgroups of 52 640 bytes = 3 x 42 units do fit).  The plan's
+// grid counts workgroups by it.
+#define WOFDM_LDS_GRANULE 1280
 static inline int wofdm_lds_workgroups_per_cu(unsigned lds_bytes)
 {
     const unsigned units = (lds_bytes + WOFDM_LDS_GRANULE - 1) / WOFDM_LDS_GRANULE;
