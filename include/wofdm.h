@@ -164,7 +164,7 @@ int wofdm_plan_set_tx_mask(wofdm_plan *plan, const float *mask);
 int wofdm_plan_status(wofdm_plan *plan);
 
 /* Kernel resource facts of the plan: {waves per workgroup, LDS bytes per workgroup,
- * workgroups launched, workgroups resident per CU (occupancy API), CUs}. */
+ * workgroups launched, workgroups resident per CU (occupancy API, capped by the LDS allocation units: DESIGN.md section 3), CUs}. */
 int wofdm_plan_info(wofdm_plan *plan, int32_t info[5]);
 
 /* Which instantiation of the frame kernel the plan launches: {layout id, variant}.  Layout: 1, 2 =
