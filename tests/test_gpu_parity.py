@@ -226,7 +226,9 @@ def test_dft_precision_matrix_pipe_vs_valu(channels, system, n_fft, cp, k):
                                                      ("WOLA", 1024, 32, 6, {}), ("WOLA", 128, 16, 4, {}),
                                                      ("wtx", 256, 32, 4, {"fir_valu": 1}), ("WOLA", 512, 32, 2, {"fir_valu": 1}),
                                                      ("wtx", 256, 32, 4, {"dft_valu": 1}), ("WOLA", 1024, 32, 6, {"dft_valu": 1}),
-                                                     ("wtx", 64, 16, 2, {}), ("WOLA", 128, 32, 6, {})])
+                                                     ("wtx", 64, 16, 2, {}), ("WOLA", 128, 32, 6, {}),
+                                                     # layout 16: two waves of eight symbols (N = 64 at CP 32), three of six (N = 128, odd stride)
+                                                     ("wtx", 64, 32, 2, {}), ("CPW", 64, 32, 4, {}), ("wrx", 128, 56, 6, {})])
 def test_production_and_instrumented_kernels_count_the_same(channels, system, n_fft, cp, k, opts):
     """The stage-by-stage parity runs the instrumented instantiations (stage stores, barriers between the phases); the same
     injected frames through the PRODUCTION instantiation of the same layout must give the same error counters (the two
