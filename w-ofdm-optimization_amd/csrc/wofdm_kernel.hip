@@ -59,13 +59,17 @@
 #define WOFDM_FFT_BIG_RADIX 1
 #endif
 
-// N = 1024: tiles whose unit noise stays in registers instead of being parked in the HBM scratch row (see phase B)
 // Received samples stored swizzled against the four-way bank conflicts of the noise-scaling stores (layouts 10 / 11 / 12, phase C)
 #ifndef WOFDM_RX_SWIZZLE
 #define WOFDM_RX_SWIZZLE 1
 #endif
+// N = 1024: tiles whose unit noise stays in registers instead of being parked in the HBM scratch row (see phase B).  All nine since
+// the end of round 4: with the transforms on the matrix pipe the kernel holds FIR outputs and noise of all tiles at 128 registers
+// with seven of them spilled (28 bytes of scratch per lane), and that beats parking any tile's noise in HBM -- 6 kept: 2.62e8,
+// 7: 2.70, 8: 2.72, 9: 2.74e8 symbols/s, C4 at full size 7.65 -> 7.30 s (interleaved A/Bs, profiles/r04_noise_keep_ab.txt).  (Round 2
+// parked all nine, round 3 three of nine: those kernels, with their transforms on the vector pipe, spilled dozens.)
 #ifndef WOFDM_NOISE_KEEP_TILES
-#define WOFDM_NOISE_KEEP_TILES 6
+#define WOFDM_NOISE_KEEP_TILES 9
 #endif
 
 // Issue priority of a wave by the phase it is in (s_setprio, 0 .. 3; round 4).  The SIMD's arbiter picks by priority, then age.  The
